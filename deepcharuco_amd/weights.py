@@ -1,0 +1,234 @@
+"""Layer tables, checkpoint reader and numpy-seeded synthetic weights.
+
+The layer tables restate the reference's module definitions:
+  detector  -> /root/reference/src/models/net.py:23-48   (dcModel.__init__)
+  refinenet -> /root/reference/src/models/refinenet.py:21-47 (RefineNet.__init__)
+
+A "state dict" here is a plain ``dict[str, np.ndarray(float32)]`` using the
+reference's own key names (``conv1a.weight``, ``bn1a.running_var`` ...), i.e.
+the Lightning checkpoint's ``state_dict`` with the ``model.`` prefix stripped
+(prefix comes from ``lModel.model = dcModel`` net.py:121 / refinenet.py:137).
+
+The pre-trained checkpoints are not shipped with the reference mount, so every
+parity fixture and the benchmark use :func:`synthetic_state_dict`, a
+deterministic ``np.random.default_rng(seed)`` generator that both the fixture
+generator (in the build container) and the GPU box can re-run.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Dict, List, NamedTuple, Optional
+
+import numpy as np
+
+StateDict = Dict[str, np.ndarray]
+
+
+class ConvSpec(NamedTuple):
+    name: str          # conv module name, e.g. "conv1b"
+    bn: Optional[str]  # following BatchNorm2d module name or None (raw 1x1 heads)
+    cin: int
+    cout: int
+    ksize: int         # 3 or 1
+    pad: int           # conv padding
+    pool: bool = False  # MaxPool2d(2,2) applied after BN+ReLU of this layer
+    ups: bool = False   # UpsamplingNearest2d(x2) applied after BN+ReLU of this layer
+
+
+def detector_specs(n_ids: int = 16) -> List[ConvSpec]:
+    """net.py:23-48 in forward order (net.py:60-77)."""
+    return [
+        ConvSpec("conv1a", "bn1a", 1, 64, 3, 1),
+        ConvSpec("conv1b", "bn1b", 64, 64, 3, 1, pool=True),
+        ConvSpec("conv2a", "bn2a", 64, 64, 3, 1),
+        ConvSpec("conv2b", "bn2b", 64, 64, 3, 1, pool=True),
+        ConvSpec("conv3a", "bn3a", 64, 128, 3, 1),
+        ConvSpec("conv3b", "bn3b", 128, 128, 3, 1, pool=True),
+        ConvSpec("conv4a", "bn4a", 128, 128, 3, 1),
+        ConvSpec("conv4b", "bn4b", 128, 128, 3, 1),
+        ConvSpec("convPa", "bnPa", 128, 256, 3, 1),
+        ConvSpec("convPb", None, 256, 65, 1, 0),
+        ConvSpec("convDa", "bnDa", 128, 256, 3, 1),
+        ConvSpec("convDb", None, 256, n_ids + 1, 1, 0),
+    ]
+
+
+def refinenet_specs() -> List[ConvSpec]:
+    """refinenet.py:21-47 in forward order (refinenet.py:56-81)."""
+    return [
+        ConvSpec("conv1a", "bn1a", 1, 64, 3, 0),
+        ConvSpec("conv1b", "bn1b", 64, 64, 3, 0),
+        ConvSpec("conv2a", "bn2a", 64, 128, 3, 0),
+        ConvSpec("conv2b", "bn2b", 128, 128, 3, 0, pool=True),
+        ConvSpec("conv3a", "bn3a", 128, 128, 3, 1),
+        ConvSpec("conv3b", "bn3b", 128, 128, 3, 1, ups=True),
+        ConvSpec("conv4a", "bn4a", 128, 128, 3, 1),
+        ConvSpec("conv4b", "bn4b", 128, 128, 3, 1, ups=True),
+        ConvSpec("conv5a", "bn5a", 128, 64, 3, 1),
+        ConvSpec("conv5b", "bn5b", 64, 64, 3, 1, ups=True),
+        ConvSpec("convPa", "bnPa", 64, 64, 3, 1),
+        ConvSpec("convPb", None, 64, 1, 1, 0),
+    ]
+
+
+def specs_for(kind: str, n_ids: int = 16) -> List[ConvSpec]:
+    if kind == "detector":
+        return detector_specs(n_ids)
+    if kind == "refinenet":
+        return refinenet_specs()
+    raise ValueError(f"unknown model kind {kind!r}")
+
+
+BN_EPS = 1e-5  # torch.nn.BatchNorm2d default, never overridden in the reference
+
+
+def state_dict_keys(kind: str, n_ids: int = 16) -> List[str]:
+    """Tensor names in the order the C-ABI ``dcx_*_create`` calls expect them."""
+    keys: List[str] = []
+    for s in specs_for(kind, n_ids):
+        keys += [f"{s.name}.weight", f"{s.name}.bias"]
+        if s.bn:
+            keys += [f"{s.bn}.weight", f"{s.bn}.bias",
+                     f"{s.bn}.running_mean", f"{s.bn}.running_var"]
+    return keys
+
+
+def synthetic_state_dict(kind: str, seed: int, n_ids: int = 16) -> StateDict:
+    """Deterministic random weights with non-trivial BN statistics.
+
+    He-normal conv weights, small biases, BN gamma~U(0.5,1.5), beta~N(0,.1),
+    running_mean~N(0,.1), running_var~U(0.5,1.5).
+    Draw order is fixed: per layer weight, bias, then the four BN tensors.
+    """
+    rng = np.random.default_rng([seed, 0 if kind == "detector" else 1])
+    sd: StateDict = {}
+    for s in specs_for(kind, n_ids):
+        fan_in = s.cin * s.ksize * s.ksize
+        w = rng.standard_normal((s.cout, s.cin, s.ksize, s.ksize), dtype=np.float32)
+        sd[f"{s.name}.weight"] = (w * np.float32(np.sqrt(2.0 / fan_in))).astype(np.float32)
+        sd[f"{s.name}.bias"] = (rng.standard_normal(s.cout, dtype=np.float32)
+                                * np.float32(0.05)).astype(np.float32)
+        if s.bn:
+            sd[f"{s.bn}.weight"] = rng.uniform(0.5, 1.5, s.cout).astype(np.float32)
+            sd[f"{s.bn}.bias"] = (rng.standard_normal(s.cout, dtype=np.float32)
+                                  * np.float32(0.1)).astype(np.float32)
+            sd[f"{s.bn}.running_mean"] = (rng.standard_normal(s.cout, dtype=np.float32)
+                                          * np.float32(0.1)).astype(np.float32)
+            sd[f"{s.bn}.running_var"] = rng.uniform(0.5, 1.5, s.cout).astype(np.float32)
+    return sd
+
+
+def state_dict_sha256(sd: StateDict, kind: str, n_ids: int = 16) -> str:
+    h = hashlib.sha256()
+    for k in state_dict_keys(kind, n_ids):
+        h.update(np.ascontiguousarray(sd[k], dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
+def validate_state_dict(sd: StateDict, kind: str, n_ids: int = 16) -> None:
+    for s in specs_for(kind, n_ids):
+        w = sd[f"{s.name}.weight"]
+        if tuple(w.shape) != (s.cout, s.cin, s.ksize, s.ksize):
+            raise ValueError(f"{kind}.{s.name}.weight has shape {tuple(w.shape)}, "
+                             f"expected {(s.cout, s.cin, s.ksize, s.ksize)}")
+        if tuple(sd[f"{s.name}.bias"].shape) != (s.cout,):
+            raise ValueError(f"{kind}.{s.name}.bias has wrong shape")
+        if s.bn:
+            for t in ("weight", "bias", "running_mean", "running_var"):
+                if tuple(sd[f"{s.bn}.{t}"].shape) != (s.cout,):
+                    raise ValueError(f"{kind}.{s.bn}.{t} has wrong shape")
+
+
+def state_dict_from_checkpoint(path: str, kind: str, n_ids: int = 16) -> StateDict:
+    """Lightning-free reader for the reference's ``.ckpt`` files.
+
+    ``lModel.load_from_checkpoint`` (inference.py:74,80) reads a ``torch.save``d
+    dict whose ``state_dict`` keys are ``model.<layer>.<tensor>``; plain
+    ``torch.save(module.state_dict())`` files (no prefix, no wrapper) load too.
+    ``num_batches_tracked`` and the torchmetrics states are ignored.
+    """
+    import torch
+    try:
+        blob = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:  # Lightning ckpts may pickle non-tensor hyper-parameters
+        blob = torch.load(path, map_location="cpu", weights_only=False)
+    raw = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
+    sd: StateDict = {}
+    for k, v in raw.items():
+        if k.startswith("model."):
+            k = k[len("model."):]
+        if k.endswith("num_batches_tracked") or not hasattr(v, "detach"):
+            continue
+        sd[k] = v.detach().to(torch.float32).cpu().numpy()
+    missing = [k for k in state_dict_keys(kind, n_ids) if k not in sd]
+    if missing:
+        raise KeyError(f"checkpoint {path} lacks {kind} tensors: {missing[:4]}...")
+    sd = {k: sd[k] for k in state_dict_keys(kind, n_ids)}
+    validate_state_dict(sd, kind, n_ids)
+    return sd
+
+
+def save_lightning_style_checkpoint(path: str, sd: StateDict) -> None:
+    """Write ``sd`` the way Lightning would (``state_dict`` + ``model.`` prefix).
+
+    Used by tests and the benchmark to exercise :func:`load_models` end to end
+    with synthetic weights.
+    """
+    import torch
+    out = {"state_dict": {f"model.{k}": torch.from_numpy(np.ascontiguousarray(v))
+                          for k, v in sd.items()},
+           "epoch": 0, "global_step": 0}
+    for k in list(out["state_dict"]):
+        if k.endswith("running_var"):
+            out["state_dict"][k.replace("running_var", "num_batches_tracked")] = torch.tensor(0)
+    torch.save(out, path)
+
+
+# --------------------------------------------------------------------------
+# synthetic frames
+
+
+def synthetic_frames(kind: str, seed: int, batch: int, height: int, width: int) -> np.ndarray:
+    """Seeded uint8 grayscale frames, shape (batch, height, width).
+
+    ``noise``: iid uniform 0..255.  ``board``: a perspective-warped checkerboard
+    over a smooth background plus mild noise, so activations have the spatial
+    structure (edges, flat regions) of a real ChArUco frame.
+    Frame ``i`` of a batch depends only on ``(kind, seed + i, height, width)``.
+    """
+    out = np.empty((batch, height, width), np.uint8)
+    for i in range(batch):
+        rng = np.random.default_rng([seed + i, height, width, 0 if kind == "noise" else 1])
+        if kind == "noise":
+            out[i] = rng.integers(0, 256, (height, width), dtype=np.uint8)
+        elif kind == "board":
+            out[i] = _board_frame(rng, height, width)
+        else:
+            raise ValueError(f"unknown frame kind {kind!r}")
+    return out
+
+
+def _board_frame(rng: np.random.Generator, h: int, w: int) -> np.ndarray:
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    # random homography close to a rotation+scale about the image centre
+    ang = rng.uniform(-0.6, 0.6)
+    sc = rng.uniform(0.5, 0.9) * min(h, w)
+    cx, cy = w / 2 + rng.uniform(-0.1, 0.1) * w, h / 2 + rng.uniform(-0.1, 0.1) * h
+    px, py = rng.uniform(-0.25, 0.25, 2) / max(h, w)
+    xr, yr = xs - cx, ys - cy
+    den = 1.0 + px * xr + py * yr
+    u = (np.cos(ang) * xr + np.sin(ang) * yr) / den / sc + 0.5
+    v = (-np.sin(ang) * xr + np.cos(ang) * yr) / den / sc + 0.5
+    inside = (u >= 0) & (u < 1) & (v >= 0) & (v < 1)
+    squares = ((np.floor(u * 5) + np.floor(v * 5)) % 2).astype(np.float64)
+    # low-frequency background
+    bg = 110 + 60 * np.sin(xs / w * rng.uniform(2, 6) + rng.uniform(0, 6)) \
+             * np.cos(ys / h * rng.uniform(2, 6) + rng.uniform(0, 6))
+    lo, hi = rng.uniform(10, 60), rng.uniform(180, 250)
+    img = np.where(inside, lo + (hi - lo) * squares, bg)
+    img = img + rng.normal(0, 4.0, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def frames_sha256(frames: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(frames).tobytes()).hexdigest()

@@ -1,0 +1,243 @@
+"""ORACLE tooling -- generates tests/golden/*.npz from the REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  It imports the
+reference's own hot-path modules (src/inference.py, src/models/*.py) with the
+four absent third-party packages stubbed (pytorch_lightning, torchmetrics,
+numba, cv2 -- none of which take part in the hot-path arithmetic except
+cv2.cvtColor, see oracle/deepcharuco_oracle.py), feeds them seeded synthetic
+weights and frames, and
+
+  1. asserts oracle/deepcharuco_oracle.py returns identical tensors
+     (torch.equal) for every hot-path function  -> pins the oracle;
+  2. writes the reference's outputs as small fixtures under tests/golden
+     (data only: inputs are regenerated from seeds and guarded by SHA-256).
+
+Usage:  python oracle/make_golden.py            (from the repo root)
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src"
+sys.path.insert(0, REPO)
+
+from deepcharuco_amd import weights as W  # noqa: E402
+from oracle import deepcharuco_oracle as O  # noqa: E402
+
+
+# ------------------------------------------------------------------ reference import
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = torch.nn.Module
+    sys.modules["pytorch_lightning"] = pl
+
+    tm = types.ModuleType("torchmetrics")
+
+    class Metric(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, default)
+    tm.Metric = Metric
+    sys.modules["torchmetrics"] = tm
+
+    nb = types.ModuleType("numba")
+    nb.njit = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda f: f))
+    nb.prange = range
+    sys.modules["numba"] = nb
+
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_BGR2GRAY = 6
+    cv2.TERM_CRITERIA_EPS = 2
+    cv2.TERM_CRITERIA_COUNT = 1
+    cv2.aruco = types.SimpleNamespace()
+
+    def cvtColor(img, code):
+        assert code == cv2.COLOR_BGR2GRAY
+        return O.bgr2gray(img)
+    cv2.cvtColor = cvtColor
+    sys.modules["cv2"] = cv2
+
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "models"))
+    os.chdir(REF)
+    import inference as ref_inf          # noqa
+    from models import net as ref_net    # noqa
+    from models import refinenet as ref_rn  # noqa
+    from models import model_utils as ref_mu  # noqa
+    return ref_inf, ref_net, ref_rn, ref_mu
+
+
+def ref_models(ref_net, ref_rn, sd_dc, sd_rn, n_ids):
+    dc = ref_net.lModel(ref_net.dcModel(n_ids))
+    missing = dc.model.load_state_dict(O.to_torch_state_dict(sd_dc), strict=False)
+    assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    assert not missing.unexpected_keys
+    dc.eval()
+    rn = ref_rn.lRefineNet(ref_rn.RefineNet())
+    missing = rn.model.load_state_dict(O.to_torch_state_dict(sd_rn), strict=False)
+    assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    rn.eval()
+    return dc, rn
+
+
+def calibrate_dustbin(dc, sd_dc, frame_u8, n_ids, target):
+    """Shift convDb.bias[n_ids] so that exactly `target` cells fire on this frame."""
+    x = torch.tensor(O.pre_bgr_image(frame_u8))
+    loc, ids = dc.infer_image(x)
+    la = loc.argmax(1)[0]
+    m = (ids[0, :n_ids].max(0).values - ids[0, n_ids])
+    m = torch.where(la == 64, torch.tensor(-1e30), m).flatten().sort(descending=True).values
+    delta = float((m[target - 1] + m[target]) / 2)
+    new_bias = np.float32(sd_dc["convDb.bias"][n_ids] + np.float32(delta))
+    sd_dc["convDb.bias"][n_ids] = new_bias
+    with torch.no_grad():
+        dc.model.convDb.bias[n_ids] = float(new_bias)
+    return float(new_bias)
+
+
+CASES = [
+    # name, weight seed, frame kind, frame seed, H, W, target K, keep full logits
+    dict(name="tiny_noise_64x96", wseed=3, kind="noise", fseed=5, H=64, W=96, K=6, full=True),
+    dict(name="noise_240x320", wseed=1234, kind="noise", fseed=0, H=240, W=320, K=16, full=True),
+    dict(name="board_240x320", wseed=1234, kind="board", fseed=1, H=240, W=320, K=16, full=False),
+    dict(name="board_480x640", wseed=7, kind="board", fseed=2, H=480, W=640, K=16, full=False),
+]
+N_IDS = 16
+
+
+def main():
+    torch.manual_seed(0)
+    ref_inf, ref_net, ref_rn, ref_mu = import_reference()
+    outdir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    index = {"torch": torch.__version__, "numpy": np.__version__,
+             "threads": torch.get_num_threads(), "cases": []}
+
+    # pre_bgr_image on every u8 value (IEEE division check for the device normaliser)
+    lut = ref_mu.pre_bgr_image(np.arange(256, dtype=np.uint8).reshape(16, 16)).reshape(256)
+    assert np.array_equal(lut, O.pre_bgr_image(np.arange(256, dtype=np.uint8).reshape(16, 16)).reshape(256))
+    np.savez_compressed(os.path.join(outdir, "pre_bgr_lut.npz"), lut=lut.astype(np.float32))
+
+    for c in CASES:
+        name = c["name"]
+        sd_dc = W.synthetic_state_dict("detector", c["wseed"], N_IDS)
+        sd_rn = W.synthetic_state_dict("refinenet", c["wseed"] + 1)
+        dc, rn = ref_models(ref_net, ref_rn, sd_dc, sd_rn, N_IDS)
+        frame = W.synthetic_frames(c["kind"], c["fseed"], 1, c["H"], c["W"])[0]
+        dust_bias = calibrate_dustbin(dc, sd_dc, frame, N_IDS, c["K"])
+        tsd_dc, tsd_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+
+        # ---- reference run, stage by stage
+        gray_f = ref_mu.pre_bgr_image(frame)
+        x = torch.tensor(gray_f)
+        loc, ids = dc.infer_image(x)
+        la, ia = ref_mu.pred_argmax(loc, ids, N_IDS)
+        kpts, ids_found = ref_mu.pred_to_keypoints(loc, ids, N_IDS)
+        assert kpts.shape[0] == c["K"], (name, kpts.shape)
+        patches = ref_mu.extract_patches(x, kpts)
+        with torch.no_grad():
+            heat = rn(patches[:, None])
+        corners_og, corners = rn.infer_patches(patches, kpts)
+        bgr = np.repeat(frame[..., None], 3, axis=2)
+        final_rn, img_out = ref_inf.infer_image(bgr, N_IDS, dc, rn, draw_pred=False, device="cpu")
+        assert img_out is bgr
+        final_norn, _ = ref_inf.infer_image(bgr, N_IDS, dc, None, draw_pred=False, device="cpu")
+
+        # ---- oracle must be identical
+        o_loc, o_ids = O.detector_infer_image(tsd_dc, x)
+        assert torch.equal(o_loc, loc) and torch.equal(o_ids, ids), f"{name}: detector logits differ"
+        o_la, o_ia = O.pred_argmax(o_loc, o_ids, N_IDS)
+        assert torch.equal(o_la, la) and torch.equal(o_ia, ia)
+        o_k, o_i = O.pred_to_keypoints(o_loc, o_ids, N_IDS)
+        assert torch.equal(o_k, kpts) and torch.equal(o_i, ids_found)
+        o_p = O.extract_patches(x, kpts)
+        assert torch.equal(o_p, patches), f"{name}: patches differ"
+        o_heat = O.refinenet_forward(tsd_rn, patches[:, None])
+        assert torch.equal(o_heat, heat), f"{name}: refinenet heat-map differs"
+        o_cog, o_c = O.refinenet_infer_patches(tsd_rn, patches, kpts)
+        assert torch.equal(o_cog, corners_og) and torch.equal(o_c, corners)
+        o_final = O.infer_image(bgr, N_IDS, tsd_dc, tsd_rn)
+        assert o_final.dtype == final_rn.dtype and np.array_equal(o_final, final_rn)
+        o_final2 = O.infer_image(bgr, N_IDS, tsd_dc, None)
+        assert o_final2.dtype == final_norn.dtype and np.array_equal(o_final2, final_norn)
+
+        # border key-points for extract_patches
+        bk = torch.tensor([[0, 0], [c["W"] - 1, c["H"] - 1], [5, c["H"] - 3], [c["W"] - 2, 7]])
+        bpatches = ref_mu.extract_patches(x, bk)
+        assert torch.equal(O.extract_patches(x, bk), bpatches)
+        assert float(bpatches[0, 12, 12]) == float(x[0, 0, 0])  # centre pixel = key-point pixel
+
+        hm = heat[:, 0].reshape(heat.shape[0], -1)
+        hm_top = torch.topk(hm, 2, dim=1).values
+        fx = dict(
+            meta=json.dumps(dict(name=name, wseed=c["wseed"], kind=c["kind"], fseed=c["fseed"],
+                                 H=c["H"], W=c["W"], n_ids=N_IDS, K=c["K"])),
+            dust_bias=np.float32(dust_bias),
+            sha_dc=W.state_dict_sha256(sd_dc, "detector", N_IDS),
+            sha_rn=W.state_dict_sha256(sd_rn, "refinenet"),
+            sha_frame=W.frames_sha256(frame),
+            loc_argmax=la[0].numpy().astype(np.int8),
+            ids_argmax=ia[0].numpy().astype(np.int8),
+            ids_argmax_raw=ids.argmax(1)[0].numpy().astype(np.int8),
+            loc_margin=O.top2_margin(loc)[0].numpy(),
+            ids_margin=O.top2_margin(ids)[0].numpy(),
+            kpts=kpts.numpy(), ids_found=ids_found.numpy(),
+            border_kpts=bk.numpy(), border_patches=bpatches.numpy(),
+            patches_first2=patches[:2].numpy(),
+            patch_sums=patches.double().sum((1, 2)).numpy(),
+            corners=corners.numpy(), corners_og=corners_og.numpy(),
+            heat_margin=(hm_top[:, 0] - hm_top[:, 1]).numpy(),
+            heat_first2=heat[:2, 0].numpy(),
+            final_rn=final_rn, final_norn=final_norn,
+        )
+        if c["full"]:
+            fx["loc_logits"] = loc[0].numpy()
+            fx["ids_logits"] = ids[0].numpy()
+        np.savez_compressed(os.path.join(outdir, f"{name}.npz"), **fx)
+
+        # ---- K == 0 behaviour (inference.py:51-52): dust-bin always wins
+        if name.startswith("tiny"):
+            sd0 = {k: v.copy() for k, v in sd_dc.items()}
+            sd0["convDb.bias"][N_IDS] = np.float32(1e4)
+            dc0, _ = ref_models(ref_net, ref_rn, sd0, sd_rn, N_IDS)
+            empty, _ = ref_inf.infer_image(bgr, N_IDS, dc0, rn, draw_pred=False, device="cpu")
+            o_empty = O.infer_image(bgr, N_IDS, O.to_torch_state_dict(sd0), tsd_rn)
+            assert empty.shape == (0,) and empty.dtype == np.float64
+            assert o_empty.shape == (0,) and o_empty.dtype == np.float64
+
+        index["cases"].append(dict(name=name, K=int(kpts.shape[0]),
+                                   min_loc_margin=float(fx["loc_margin"].min()),
+                                   min_ids_margin=float(fx["ids_margin"].min()),
+                                   min_heat_margin=float(fx["heat_margin"].min())))
+        print(f"[golden] {name}: K={kpts.shape[0]} dust_bias={dust_bias:.6f} "
+              f"min margins loc {fx['loc_margin'].min():.2e} ids {fx['ids_margin'].min():.2e} "
+              f"heat {fx['heat_margin'].min():.2e}; oracle == reference")
+
+    # BGR -> gray restatement on a colour image (cv2 absent: parity unpinned, formula only)
+    rng = np.random.default_rng(99)
+    bgr = rng.integers(0, 256, (16, 24, 3), dtype=np.uint8)
+    np.savez_compressed(os.path.join(outdir, "bgr2gray_formula.npz"), bgr=bgr, gray=O.bgr2gray(bgr))
+
+    # solve_pnp object-point construction (inference.py:15-26), before cv2.solvePnP
+    kp = np.array([[10.5, 20.25, 3], [100.0, 50.0, 0], [30.0, 31.0, 15], [7.0, 8.0, 9]])
+    objp, imgp = O.solve_pnp_object_points(kp, 5, 5, 0.01)
+    np.savez_compressed(os.path.join(outdir, "solve_pnp_points.npz"), kp=kp, objp=objp, imgp=imgp)
+
+    with open(os.path.join(outdir, "index.json"), "w") as f:
+        json.dump(index, f, indent=1)
+    print("[golden] wrote", outdir)
+
+
+if __name__ == "__main__":
+    main()
