@@ -1,0 +1,528 @@
+// dcx_api.hip -- C ABI of libdeepcharuco_amd.so: model handles, weight packing, the layer
+// chains of both networks and the sync-free batched pipeline.  See include/deepcharuco_amd.h.
+#include "dcx_common.h"
+
+#include <math.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr float kBnEps = 1e-5f;   // torch.nn.BatchNorm2d default (never overridden by the reference)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- host-side packing ---------------------------------------------------------------------
+
+// OIHW -> [tap][cin/4][cout_pad][4 = cin % 4], zero padded in cout.
+std::vector<float> pack_conv(const float* w, int cout, int cin, int ks, int cout_pad) {
+    const int taps = ks * ks, cq = cin / 4;
+    std::vector<float> out((size_t)taps * cq * cout_pad * 4, 0.0f);
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i)
+            for (int t = 0; t < taps; ++t)
+                out[(((size_t)t * cq + (i >> 2)) * cout_pad + o) * 4 + (i & 3)] = w[((size_t)o * cin + i) * taps + t];
+    return out;
+}
+
+// eval-mode BatchNorm2d as ATen's CPU inference path evaluates it: y = x * alpha + beta with
+// alpha = gamma * (1 / sqrt(var + eps)), beta = bn_bias - mean * alpha   (fp32 throughout).
+void fold_bn(const float* gamma, const float* bbeta, const float* mean, const float* var, int c, int c_pad,
+             std::vector<float>& alpha, std::vector<float>& beta) {
+    alpha.assign(c_pad, 0.0f);
+    beta.assign(c_pad, 0.0f);
+    for (int i = 0; i < c; ++i) {
+        const float inv = 1.0f / sqrtf(var[i] + kBnEps);
+        const float a = gamma[i] * inv;
+        alpha[i] = a;
+        beta[i] = bbeta[i] - mean[i] * a;
+    }
+}
+
+std::vector<float> pad_vec(const float* v, int c, int c_pad) {
+    std::vector<float> out(c_pad, 0.0f);
+    memcpy(out.data(), v, sizeof(float) * c);
+    return out;
+}
+
+struct DevLayer {       // one MFMA convolution's parameters on the device
+    float* w = nullptr;
+    float* bias = nullptr;
+    float* alpha = nullptr;
+    float* beta = nullptr;
+    int cin = 0, cout = 0, cout_pad = 0, ks = 3;
+};
+
+int upload(const std::vector<float>& h, float** d) {
+    DCX_CHECK_HIP(hipMalloc((void**)d, h.size() * sizeof(float)));
+    DCX_CHECK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void free_layer(DevLayer& l) {
+    if (l.w) (void)hipFree(l.w);
+    if (l.bias) (void)hipFree(l.bias);
+    if (l.alpha) (void)hipFree(l.alpha);
+    if (l.beta) (void)hipFree(l.beta);
+    l = DevLayer();
+}
+
+// weight/bias (+ optional BN) host pointers of one conv, in state_dict_keys() order
+struct HostConv {
+    const float* w; const float* b;
+    const float* g; const float* be; const float* mu; const float* var;   // null when no BN follows
+};
+
+int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out) {
+    DevLayer l;
+    l.cin = cin; l.cout = cout; l.ks = ks;
+    l.cout_pad = dcx_conv_cout_pad(cout);
+    int rc = upload(pack_conv(h.w, cout, cin, ks, l.cout_pad), &l.w);
+    if (rc == 0) rc = upload(pad_vec(h.b, cout, l.cout_pad), &l.bias);
+    if (rc == 0 && h.g != nullptr) {
+        std::vector<float> al, be;
+        fold_bn(h.g, h.be, h.mu, h.var, cout, l.cout_pad, al, be);
+        rc = upload(al, &l.alpha);
+        if (rc == 0) rc = upload(be, &l.beta);
+    }
+    if (rc != 0) { free_layer(l); return rc; }
+    *out = l;
+    return 0;
+}
+
+// Cin = 1 first layer: weights as [tap][64]
+int make_first_layer(const HostConv& h, DevLayer* out) {
+    DevLayer l;
+    l.cin = 1; l.cout = 64; l.cout_pad = 64; l.ks = 3;
+    std::vector<float> w(9 * 64);
+    for (int o = 0; o < 64; ++o)
+        for (int t = 0; t < 9; ++t) w[t * 64 + o] = h.w[o * 9 + t];
+    std::vector<float> al, be;
+    fold_bn(h.g, h.be, h.mu, h.var, 64, 64, al, be);
+    int rc = upload(w, &l.w);
+    if (rc == 0) rc = upload(pad_vec(h.b, 64, 64), &l.bias);
+    if (rc == 0) rc = upload(al, &l.alpha);
+    if (rc == 0) rc = upload(be, &l.beta);
+    if (rc != 0) { free_layer(l); return rc; }
+    *out = l;
+    return 0;
+}
+
+// ---- timing ---------------------------------------------------------------------------------
+bool g_timing = false;
+hipEvent_t g_ev[5];
+bool g_ev_ok = false;
+int timing_mark(int i, hipStream_t s) {
+    if (!g_timing) return 0;
+    if (!g_ev_ok) {
+        for (auto& e : g_ev) DCX_CHECK_HIP(hipEventCreate(&e));
+        g_ev_ok = true;
+    }
+    DCX_CHECK_HIP(hipEventRecord(g_ev[i], s));
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+struct dcx_detector {
+    int n_ids = 16;
+    DevLayer first;                 // conv1a
+    DevLayer enc[7];                // conv1b conv2a conv2b conv3a conv3b conv4a conv4b
+    DevLayer heads_a;               // convPa | convDa fused along cout (128 -> 512)
+    DevLayer head_loc, head_ids;    // convPb (256 -> 65), convDb (256 -> n_ids+1), 1x1 raw
+};
+
+struct dcx_refiner {
+    DevLayer first;                 // conv1a
+    DevLayer mid[9];                // conv1b conv2a conv2b conv3a conv3b conv4a conv4b conv5a conv5b
+    DevLayer head_a;                // convPa (64 -> 64)
+    float* head_w = nullptr;        // convPb weights [64]
+    float head_b = 0.f;
+};
+
+namespace {
+
+struct DetWs {
+    size_t buf0, buf1, loc, ids, total;
+    int ids_quads;
+};
+DetWs det_layout(int n_ids, int b, int h, int w) {
+    DetWs L;
+    const size_t hw = (size_t)h * w, cells = hw / 64;
+    L.ids_quads = (n_ids + 1 + 3) / 4;
+    size_t off = 0;
+    L.buf0 = off; off = align_up(off + (size_t)b * 64 * hw * 4, 256);
+    L.buf1 = off; off = align_up(off + (size_t)b * 16 * hw * 4, 256);
+    L.loc = off;  off = align_up(off + (size_t)b * 68 * cells * 4, 256);
+    L.ids = off;  off = align_up(off + (size_t)b * L.ids_quads * 4 * cells * 4, 256);
+    L.total = off;
+    return L;
+}
+
+struct RefWs {
+    size_t buf0, buf1, pval, pidx, total;
+};
+constexpr int kRefTiles = 16;     // 64x64 heat-map in 8x32 tiles
+RefWs ref_layout(int p) {
+    RefWs L;
+    size_t off = 0;
+    L.buf0 = off; off = align_up(off + (size_t)p * 65536 * 4, 256);
+    L.buf1 = off; off = align_up(off + (size_t)p * 65536 * 4, 256);
+    L.pval = off; off = align_up(off + (size_t)p * kRefTiles * 4, 256);
+    L.pidx = off; off = align_up(off + (size_t)p * kRefTiles * 4, 256);
+    L.total = off;
+    return L;
+}
+
+DcxConvArgs conv_args(const DevLayer& l, const float* in, int n, int in_cq_total, int in_cq_off, int hin, int win,
+                      int ups, int pad, float* out, int out_cq_total, const int* n_limit) {
+    DcxConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.w = l.w; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
+    a.n_limit = n_limit;
+    a.n = n; a.in_cq_total = in_cq_total; a.in_cq_off = in_cq_off; a.cin = l.cin;
+    a.hin = hin; a.win = win; a.ups = ups; a.pad = pad;
+    a.ho = (hin << ups) + 2 * pad - (l.ks - 1);
+    a.wo = (win << ups) + 2 * pad - (l.ks - 1);
+    a.out_cq_total = out_cq_total; a.out_cq_off = 0;
+    a.cout_pad = l.cout_pad; a.cout_quads = (l.cout + 3) / 4; a.cout_real = l.cout;
+    return a;
+}
+
+}  // namespace
+
+extern "C" const char* dcx_version(void) { return "deepcharuco_amd 0.1 (gfx950, fp32 MFMA)"; }
+
+extern "C" const char* dcx_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case DCX_E_ARG: return "DCX_E_ARG: null pointer or bad scalar argument";
+        case DCX_E_SHAPE: return "DCX_E_SHAPE: unsupported shape (H/W must be multiples of 8, patches 24x24, ...)";
+        case DCX_E_WS: return "DCX_E_WS: workspace too small";
+        case DCX_E_NIDS: return "DCX_E_NIDS: dust_bin / n_ids mismatch";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dcx error";
+    }
+}
+
+// ---- detector ---------------------------------------------------------------------------------
+extern "C" int dcx_detector_create(dcx_detector** out, const float* const* t, int n_tensors, int n_ids) {
+    if (!out || !t) return DCX_E_ARG;
+    if (n_ids < 1 || n_ids > 62) return DCX_E_NIDS;
+    if (n_tensors != 64) return DCX_E_ARG;   // 10 conv+BN (6 tensors) + 2 raw convs (2 tensors)
+    for (int i = 0; i < n_tensors; ++i)
+        if (!t[i]) return DCX_E_ARG;
+    dcx_detector* d = new (std::nothrow) dcx_detector();
+    if (!d) return (int)hipErrorOutOfMemory;
+    d->n_ids = n_ids;
+    auto hc = [&](int base, bool bn) {
+        return HostConv{t[base], t[base + 1], bn ? t[base + 2] : nullptr, bn ? t[base + 3] : nullptr,
+                        bn ? t[base + 4] : nullptr, bn ? t[base + 5] : nullptr};
+    };
+    // tensor index of each conv in state_dict_keys("detector") order
+    // conv1a 0, conv1b 6, conv2a 12, conv2b 18, conv3a 24, conv3b 30, conv4a 36, conv4b 42,
+    // convPa 48, convPb 54, convDa 56, convDb 62
+    static const int enc_cin[7] = {64, 64, 64, 64, 128, 128, 128};
+    static const int enc_cout[7] = {64, 64, 64, 128, 128, 128, 128};
+    int rc = make_first_layer(hc(0, true), &d->first);
+    for (int i = 0; rc == 0 && i < 7; ++i) rc = make_layer(hc(6 + 6 * i, true), enc_cin[i], enc_cout[i], 3, &d->enc[i]);
+    if (rc == 0) {   // fuse convPa | convDa: same input, 128 -> 256 + 256
+        const HostConv pa = hc(48, true), da = hc(56, true);
+        const size_t wsz = (size_t)256 * 128 * 9;
+        std::vector<float> w(2 * wsz), b(512), g(512), be(512), mu(512), var(512);
+        memcpy(w.data(), pa.w, wsz * 4); memcpy(w.data() + wsz, da.w, wsz * 4);
+        auto cat = [](std::vector<float>& dst, const float* x, const float* y) {
+            memcpy(dst.data(), x, 256 * 4); memcpy(dst.data() + 256, y, 256 * 4);
+        };
+        cat(b, pa.b, da.b); cat(g, pa.g, da.g); cat(be, pa.be, da.be); cat(mu, pa.mu, da.mu); cat(var, pa.var, da.var);
+        rc = make_layer(HostConv{w.data(), b.data(), g.data(), be.data(), mu.data(), var.data()}, 128, 512, 3,
+                        &d->heads_a);
+    }
+    if (rc == 0) rc = make_layer(hc(54, false), 256, 65, 1, &d->head_loc);
+    if (rc == 0) rc = make_layer(hc(62, false), 256, n_ids + 1, 1, &d->head_ids);
+    if (rc != 0) { dcx_detector_destroy(d); return rc; }
+    *out = d;
+    return 0;
+}
+
+extern "C" int dcx_detector_destroy(dcx_detector* d) {
+    if (!d) return 0;
+    free_layer(d->first);
+    for (auto& l : d->enc) free_layer(l);
+    free_layer(d->heads_a); free_layer(d->head_loc); free_layer(d->head_ids);
+    delete d;
+    return 0;
+}
+
+extern "C" size_t dcx_detector_workspace_bytes(const dcx_detector* det, int batch, int height, int width) {
+    if (!det || batch <= 0 || height <= 0 || width <= 0) return 0;
+    return det_layout(det->n_ids, batch, height, width).total;
+}
+
+extern "C" int dcx_detector_forward(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch,
+                                    const float* d_images_f32, int batch, int height, int width, void* d_ws,
+                                    size_t ws_bytes, float* d_loc_nchw, float* d_ids_nchw, void* stream) {
+    if (!det || !d_ws) return DCX_E_ARG;
+    if ((d_frames_u8 == nullptr) == (d_images_f32 == nullptr)) return DCX_E_ARG;
+    if (batch <= 0 || height < 8 || width < 8 || (height & 7) || (width & 7)) return DCX_E_SHAPE;
+    const DetWs L = det_layout(det->n_ids, batch, height, width);
+    if (ws_bytes < L.total) return DCX_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    float* buf0 = (float*)(ws + L.buf0);
+    float* buf1 = (float*)(ws + L.buf1);
+    float* loc = (float*)(ws + L.loc);
+    float* ids = (float*)(ws + L.ids);
+    const int h = height, w = width;
+    int rc;
+    // conv1a + bn1a + relu (net.py:60)
+    if (d_frames_u8)
+        rc = dcx_launch_conv1_u8(d_frames_u8, frame_stride, pitch, batch, h, w, 1, det->first.w, det->first.bias,
+                                 det->first.alpha, det->first.beta, buf0, nullptr, s);
+    else
+        rc = dcx_launch_conv1_f32(d_images_f32, (long)h * w, w, batch, h, w, 1, det->first.w, det->first.bias,
+                                  det->first.alpha, det->first.beta, buf0, nullptr, s);
+    if (rc) return rc;
+    // encoder (net.py:61-70): {layer, input divisor, pool}
+    struct Step { int layer, div, pool; };
+    static const Step steps[7] = {{0, 1, 1}, {1, 2, 0}, {2, 2, 1}, {3, 4, 0}, {4, 4, 1}, {5, 8, 0}, {6, 8, 0}};
+    float* src = buf0;
+    float* dst = buf1;
+    for (const Step& st : steps) {
+        const DevLayer& l = det->enc[st.layer];
+        DcxConvArgs a = conv_args(l, src, batch, l.cin / 4, 0, h / st.div, w / st.div, 0, 1, dst, l.cout / 4, nullptr);
+        rc = dcx_launch_conv_mfma(a, 3, st.pool, DCX_EPI_BNRELU, s);
+        if (rc) return rc;
+        float* t = src; src = dst; dst = t;
+    }
+    // after 7 steps: src = buf1 holds conv4b output (128 ch @ H/8 x W/8), dst = buf0
+    const int hc = h / 8, wc = w / 8;
+    {   // convPa|convDa + BN + ReLU (net.py:73,76) -> 512 channels
+        DcxConvArgs a = conv_args(det->heads_a, src, batch, 32, 0, hc, wc, 0, 1, dst, 128, nullptr);
+        rc = dcx_launch_conv_mfma(a, 3, 0, DCX_EPI_BNRELU, s);
+        if (rc) return rc;
+    }
+    {   // convPb 1x1 (net.py:74): channels 0..255 -> 65 logits; image flattened to 1 x cells
+        DcxConvArgs a = conv_args(det->head_loc, dst, batch, 128, 0, 1, hc * wc, 0, 0, loc, 17, nullptr);
+        rc = dcx_launch_conv_mfma(a, 1, 0, DCX_EPI_RAW, s);
+        if (rc) return rc;
+    }
+    {   // convDb 1x1 (net.py:77): channels 256..511 -> n_ids+1 logits
+        DcxConvArgs a = conv_args(det->head_ids, dst, batch, 128, 64, 1, hc * wc, 0, 0, ids, L.ids_quads, nullptr);
+        rc = dcx_launch_conv_mfma(a, 1, 0, DCX_EPI_RAW, s);
+        if (rc) return rc;
+    }
+    if (d_loc_nchw) { rc = dcx_c4_to_nchw(loc, batch, 65, hc, wc, d_loc_nchw, stream); if (rc) return rc; }
+    if (d_ids_nchw) { rc = dcx_c4_to_nchw(ids, batch, det->n_ids + 1, hc, wc, d_ids_nchw, stream); if (rc) return rc; }
+    return 0;
+}
+
+extern "C" int dcx_detector_decode(const dcx_detector* det, int batch, int height, int width, const void* d_ws,
+                                   int dust_bin, int kmax, int32_t* d_counts, int32_t* d_rows, int32_t* d_loc_argmax,
+                                   int32_t* d_ids_argmax, void* stream) {
+    if (!det || !d_ws) return DCX_E_ARG;
+    if (batch <= 0 || height < 8 || width < 8 || (height & 7) || (width & 7)) return DCX_E_SHAPE;
+    const DetWs L = det_layout(det->n_ids, batch, height, width);
+    const int hc = height / 8, wc = width / 8;
+    const long cells = (long)hc * wc;
+    const char* ws = (const char*)d_ws;
+    DcxLogitView lv{(const float*)(ws + L.loc), 17 * 4 * cells, 4 * cells, 4, 1};
+    DcxLogitView iv{(const float*)(ws + L.ids), (long)L.ids_quads * 4 * cells, 4 * cells, 4, 1};
+    return dcx_launch_decode(lv, iv, batch, 65, det->n_ids + 1, hc, wc, dust_bin, kmax, d_counts, d_rows,
+                             d_loc_argmax, d_ids_argmax, (hipStream_t)stream);
+}
+
+// ---- refiner ----------------------------------------------------------------------------------
+extern "C" int dcx_refiner_create(dcx_refiner** out, const float* const* t, int n_tensors) {
+    if (!out || !t) return DCX_E_ARG;
+    if (n_tensors != 68) return DCX_E_ARG;   // 11 conv+BN (6 tensors) + convPb (2 tensors)
+    for (int i = 0; i < n_tensors; ++i)
+        if (!t[i]) return DCX_E_ARG;
+    dcx_refiner* r = new (std::nothrow) dcx_refiner();
+    if (!r) return (int)hipErrorOutOfMemory;
+    auto hc = [&](int base) { return HostConv{t[base], t[base + 1], t[base + 2], t[base + 3], t[base + 4], t[base + 5]}; };
+    // conv1a 0, conv1b 6, conv2a 12, conv2b 18, conv3a 24, conv3b 30, conv4a 36, conv4b 42, conv5a 48,
+    // conv5b 54, convPa 60, convPb 66
+    static const int cin[9] = {64, 64, 128, 128, 128, 128, 128, 128, 64};
+    static const int cout[9] = {64, 128, 128, 128, 128, 128, 128, 64, 64};
+    int rc = make_first_layer(hc(0), &r->first);
+    for (int i = 0; rc == 0 && i < 9; ++i) rc = make_layer(hc(6 + 6 * i), cin[i], cout[i], 3, &r->mid[i]);
+    if (rc == 0) rc = make_layer(hc(60), 64, 64, 3, &r->head_a);
+    if (rc == 0) {
+        std::vector<float> hw(t[66], t[66] + 64);   // convPb.weight (1,64,1,1)
+        rc = upload(hw, &r->head_w);
+        r->head_b = t[67][0];
+    }
+    if (rc != 0) { dcx_refiner_destroy(r); return rc; }
+    *out = r;
+    return 0;
+}
+
+extern "C" int dcx_refiner_destroy(dcx_refiner* r) {
+    if (!r) return 0;
+    free_layer(r->first);
+    for (auto& l : r->mid) free_layer(l);
+    free_layer(r->head_a);
+    if (r->head_w) (void)hipFree(r->head_w);
+    delete r;
+    return 0;
+}
+
+extern "C" size_t dcx_refiner_workspace_bytes(const dcx_refiner* rf, int max_patches) {
+    if (!rf || max_patches <= 0) return 0;
+    return ref_layout(max_patches).total;
+}
+
+extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches, int max_patches,
+                                   const int32_t* d_total, const int32_t* d_table, void* d_ws, size_t ws_bytes,
+                                   int32_t* d_corners, float* d_xy, float* d_heat, void* stream) {
+    if (!rf || !d_patches || !d_ws) return DCX_E_ARG;
+    if (d_xy != nullptr && d_table == nullptr) return DCX_E_ARG;
+    if (max_patches <= 0 || max_patches > 65535) return DCX_E_SHAPE;
+    const RefWs L = ref_layout(max_patches);
+    if (ws_bytes < L.total) return DCX_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    float* buf0 = (float*)(ws + L.buf0);
+    float* buf1 = (float*)(ws + L.buf1);
+    const int p = max_patches;
+    const int* lim = d_total;
+    // conv1a (pad 0) 24 -> 22 (refinenet.py:56)
+    int rc = dcx_launch_conv1_f32(d_patches, 576, 24, p, 24, 24, 0, rf->first.w, rf->first.bias, rf->first.alpha,
+                                  rf->first.beta, buf0, lim, s);
+    if (rc) return rc;
+    // refinenet.py:57-78: {layer, input size, ups-on-read, pad, pool}
+    struct Step { int layer, hin, ups, pad, pool; };
+    static const Step steps[9] = {
+        {0, 22, 0, 0, 0},   // conv1b 22 -> 20
+        {1, 20, 0, 0, 0},   // conv2a 20 -> 18
+        {2, 18, 0, 0, 1},   // conv2b 18 -> 16 -> pool 8
+        {3, 8, 0, 1, 0},    // conv3a
+        {4, 8, 0, 1, 0},    // conv3b (its x2 up-sampling is applied by the next layer's read)
+        {5, 8, 1, 1, 0},    // conv4a on 16x16
+        {6, 16, 0, 1, 0},   // conv4b
+        {7, 16, 1, 1, 0},   // conv5a on 32x32
+        {8, 32, 0, 1, 0},   // conv5b
+    };
+    float* src = buf0;
+    float* dst = buf1;
+    for (const Step& st : steps) {
+        const DevLayer& l = rf->mid[st.layer];
+        DcxConvArgs a = conv_args(l, src, p, l.cin / 4, 0, st.hin, st.hin, st.ups, st.pad, dst, l.cout / 4, lim);
+        rc = dcx_launch_conv_mfma(a, 3, st.pool, DCX_EPI_BNRELU, s);
+        if (rc) return rc;
+        float* t = src; src = dst; dst = t;
+    }
+    {   // convPa on the up-sampled 64x64 + BN + ReLU + convPb 1x1 + per-tile arg-max (refinenet.py:80-81,108-111)
+        DcxConvArgs a = conv_args(rf->head_a, src, p, 16, 0, 32, 32, 1, 1, nullptr, 16, lim);
+        a.head_w = rf->head_w; a.head_b = rf->head_b; a.heat = d_heat;
+        a.part_val = (float*)(ws + L.pval); a.part_idx = (int*)(ws + L.pidx);
+        if (dcx_conv_heat_tiles(a.ho, a.wo) != kRefTiles) return DCX_E_SHAPE;
+        rc = dcx_launch_conv_mfma(a, 3, 0, DCX_EPI_HEAT, s);
+        if (rc) return rc;
+    }
+    return dcx_launch_refine_finalize((const float*)(ws + L.pval), (const int*)(ws + L.pidx), kRefTiles, 64, p, lim,
+                                      d_table, d_corners, d_xy, s);
+}
+
+// ---- whole pipeline -----------------------------------------------------------------------------
+namespace {
+struct PipeWs { size_t det, table, total_i, patches, ref, total; };
+PipeWs pipe_layout(const dcx_detector* det, const dcx_refiner* rf, int b, int h, int w, int kmax) {
+    PipeWs L;
+    const size_t p = (size_t)b * kmax;
+    size_t off = 0;
+    L.det = off; off = align_up(off + det_layout(det->n_ids, b, h, w).total, 256);
+    L.table = off; off = align_up(off + p * 16, 256);
+    L.total_i = off; off = align_up(off + 256, 256);
+    L.patches = off; off = align_up(off + (rf ? p * 576 * 4 : 0), 256);
+    L.ref = off; off = align_up(off + (rf ? ref_layout((int)p).total : 0), 256);
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t dcx_pipeline_workspace_bytes(const dcx_detector* det, const dcx_refiner* rf, int batch, int height,
+                                               int width, int kmax) {
+    if (!det || batch <= 0 || height <= 0 || width <= 0 || kmax <= 0) return 0;
+    return pipe_layout(det, rf, batch, height, width, kmax).total;
+}
+
+extern "C" int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d_frames_u8,
+                               long frame_stride, int pitch, int batch, int height, int width, int dust_bin, int kmax,
+                               void* d_ws, size_t ws_bytes, int32_t* d_counts, int32_t* d_rows, float* d_xy,
+                               void* stream) {
+    if (!det || !d_frames_u8 || !d_ws || !d_counts || !d_rows) return DCX_E_ARG;
+    if (rf != nullptr && d_xy == nullptr) return DCX_E_ARG;
+    if (kmax <= 0 || (long)batch * kmax > 65535) return DCX_E_SHAPE;
+    const PipeWs L = pipe_layout(det, rf, batch, height, width, kmax);
+    if (ws_bytes < L.total) return DCX_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d_ws;
+    int rc = timing_mark(0, s);
+    if (rc) return rc;
+    rc = dcx_detector_forward(det, d_frames_u8, frame_stride, pitch, nullptr, batch, height, width, ws + L.det,
+                              L.table - L.det, nullptr, nullptr, stream);
+    if (rc) return rc;
+    if ((rc = timing_mark(1, s))) return rc;
+    rc = dcx_detector_decode(det, batch, height, width, ws + L.det, dust_bin, kmax, d_counts, d_rows, nullptr, nullptr,
+                             stream);
+    if (rc) return rc;
+    if (rf == nullptr) {
+        if ((rc = timing_mark(2, s))) return rc;
+        if ((rc = timing_mark(3, s))) return rc;
+        return 0;
+    }
+    int32_t* table = (int32_t*)(ws + L.table);
+    int32_t* total = (int32_t*)(ws + L.total_i);
+    const int p = batch * kmax;
+    rc = dcx_build_patch_table(d_counts, d_rows, batch, kmax, table, total, stream);
+    if (rc) return rc;
+    rc = dcx_extract_patches_u8(d_frames_u8, frame_stride, pitch, height, width, table, total, p,
+                                (float*)(ws + L.patches), stream);
+    if (rc) return rc;
+    if ((rc = timing_mark(2, s))) return rc;
+    rc = dcx_refiner_forward(rf, (const float*)(ws + L.patches), p, total, table, ws + L.ref, L.total - L.ref, nullptr,
+                             d_xy, nullptr, stream);
+    if (rc) return rc;
+    return timing_mark(3, s);
+}
+
+extern "C" int dcx_set_timing(int enabled) { g_timing = enabled != 0; return 0; }
+
+extern "C" int dcx_last_timings(float* h_ms4) {
+    if (!h_ms4) return DCX_E_ARG;
+    if (!g_ev_ok) return DCX_E_ARG;
+    DCX_CHECK_HIP(hipEventElapsedTime(&h_ms4[0], g_ev[0], g_ev[1]));
+    DCX_CHECK_HIP(hipEventElapsedTime(&h_ms4[1], g_ev[1], g_ev[2]));
+    DCX_CHECK_HIP(hipEventElapsedTime(&h_ms4[2], g_ev[2], g_ev[3]));
+    DCX_CHECK_HIP(hipEventElapsedTime(&h_ms4[3], g_ev[0], g_ev[3]));
+    return 0;
+}
+
+// ---- stage-level test entry -----------------------------------------------------------------------
+extern "C" int dcx_conv_layer(const float* d_in, int n, int cin, int hin, int win, const float* h_w, const float* h_b,
+                              const float* h_g, const float* h_be, const float* h_mu, const float* h_var, int cout,
+                              int ksize, int pad, int ups, int pool, int relu, float* d_out, void* stream) {
+    if (!d_in || !h_w || !h_b || !d_out) return DCX_E_ARG;
+    if (cin % 32 != 0 || (ksize != 3 && ksize != 1) || n <= 0) return DCX_E_SHAPE;
+    const bool bn = h_g != nullptr;
+    if (bn != (relu != 0)) return DCX_E_ARG;   // kernels implement conv+BN+ReLU or raw conv+bias
+    if (bn && (!h_be || !h_mu || !h_var)) return DCX_E_ARG;
+    DevLayer l;
+    int rc = make_layer(HostConv{h_w, h_b, h_g, h_be, h_mu, h_var}, cin, cout, ksize, &l);
+    if (rc) return rc;
+    DcxConvArgs a;
+    if (ksize == 1) {
+        if (pad != 0 || ups != 0 || pool != 0) { free_layer(l); return DCX_E_SHAPE; }
+        a = conv_args(l, d_in, n, cin / 4, 0, 1, hin * win, 0, 0, d_out, (cout + 3) / 4, nullptr);
+    } else {
+        a = conv_args(l, d_in, n, cin / 4, 0, hin, win, ups, pad, d_out, (cout + 3) / 4, nullptr);
+    }
+    rc = dcx_launch_conv_mfma(a, ksize, pool, bn ? DCX_EPI_BNRELU : DCX_EPI_RAW, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    free_layer(l);
+    if (rc) return rc;
+    return (int)e;
+}

@@ -1,0 +1,81 @@
+// dcx_common.h -- internal declarations shared by the HIP translation units.
+// gfx950 (MI355X, CDNA4) only: wave64, v_mfma_f32_32x32x2_f32, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/deepcharuco_amd.h"
+
+#define DCX_CHECK_HIP(expr)                              \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return (int)_e;            \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// MFMA convolution (dcx_conv_mfma.hip)
+
+enum DcxEpilogue {
+    DCX_EPI_BNRELU = 0,  // y = relu(fma(acc + bias, alpha, beta))
+    DCX_EPI_RAW = 1,     // y = acc + bias                     (1x1 heads, "NO activ" net.py:74,77)
+    DCX_EPI_HEAT = 2,    // BN+ReLU, then 1x1 conv to ONE channel + per-tile arg-max (RefineNet head)
+};
+
+struct DcxConvArgs {
+    const float* in;       // C4 [N][in_cq_total][Hin][Win][4]
+    const float* w;        // packed [ks*ks][cin/4][cout_pad][4]   (4 = cin % 4)
+    const float* bias;     // [cout_pad]
+    const float* alpha;    // [cout_pad]  gamma / sqrt(var + eps)
+    const float* beta;     // [cout_pad]  bn_beta - mean * alpha
+    float* out;            // C4 [N][out_cq_total][Hs][Ws][4]; Hs = Ho (or Ho/2 when pooled)
+    const int* n_limit;    // optional device int: images n >= *n_limit are skipped
+    // DCX_EPI_HEAT only
+    const float* head_w;   // [cout_pad] weights of the 1x1 conv to one channel
+    float head_b;
+    float* heat;           // nullable [N][Ho][Wo] raw heat-map
+    float* part_val;       // [N][tiles] per-tile maximum
+    int* part_idx;         // [N][tiles] flat index (y*Wo+x) of the first maximum in the tile
+    int n;
+    int in_cq_total, in_cq_off;
+    int cin;               // multiple of 32
+    int hin, win;          // physical input size
+    int ups;               // 1: input is read through a nearest x2 up-sampling
+    int pad;               // 0 or 1 (ks == 3), 0 (ks == 1)
+    int ho, wo;            // convolution output size (before pooling)
+    int out_cq_total, out_cq_off;
+    int cout_pad;          // multiple of the kernel's COUT_TILE
+    int cout_quads;        // valid output channel quads = ceil(cout / 4)
+    int cout_real;         // un-padded output channels (profiling only)
+    int tiles_x, tiles_y;
+};
+
+// Picks a tile configuration for (ho, wo, cout_pad, pool, epi, ks) and launches.
+// Returns 0 / DCX_E_SHAPE / hipError_t.
+int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t stream);
+// Rounds cout up to what dcx_launch_conv_mfma needs for cout_pad.
+int dcx_conv_cout_pad(int cout);
+// Number of spatial tiles the DCX_EPI_HEAT launch will use for (ho, wo) (size of part_* per image).
+int dcx_conv_heat_tiles(int ho, int wo);
+
+// ---------------------------------------------------------------------------------------
+// everything else (dcx_misc.hip)
+
+int dcx_launch_conv1_u8(const uint8_t* frames, long frame_stride, int pitch, int n, int h, int w, int pad,
+                        const float* w9x64, const float* bias, const float* alpha, const float* beta,
+                        float* out_c4, const int* n_limit, hipStream_t s);
+int dcx_launch_conv1_f32(const float* images, long image_stride, int pitch, int n, int h, int w, int pad,
+                         const float* w9x64, const float* bias, const float* alpha, const float* beta,
+                         float* out_c4, const int* n_limit, hipStream_t s);
+
+// strided logits accessor: value(b, c, cell) = p[b*sb + (c>>2)*sq + cell*sp + (c&3)*sc]
+struct DcxLogitView {
+    const float* p;
+    long sb, sq, sp, sc;
+};
+int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, int n_ids1, int hc, int wc,
+                      int dust_bin, int kmax, int32_t* counts, int32_t* rows,
+                      int32_t* loc_argmax, int32_t* ids_argmax, hipStream_t s);
+int dcx_launch_refine_finalize(const float* part_val, const int* part_idx, int tiles, int wo,
+                               int max_patches, const int* total, const int32_t* table,
+                               int32_t* corners, float* xy, hipStream_t s);

@@ -1,0 +1,128 @@
+// dcx_conv_mfma.hip -- instantiations and tile selection for the MFMA convolution kernel.
+#include "dcx_conv_mfma.h"
+
+#include <vector>
+
+namespace {
+
+struct CfgEntry {
+    int cout_tile, cap, th, tw, ks, pool, epi;
+    int (*launch)(DcxConvArgs, hipStream_t);
+    const char* name;
+};
+
+#define DCX_CFG(WM, WN, MT, NT, TH, TW, KS, POOL, EPI)                                              \
+    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI,                                             \
+      &dcx_conv_launch_cfg<DcxConvCfg<WM, WN, MT, NT, TH, TW, KS, (POOL) != 0, EPI>>,                 \
+      "dcx_conv_mfma_kernel<DcxConvCfg<" #WM "," #WN "," #MT "," #NT "," #TH "," #TW "," #KS "," #POOL "," #EPI ">>" }
+
+// Wave layouts:  A = 1x4 waves, 64 couts x 256 px   B = 2x2 waves, 128 couts x 128 px
+//                C = 4x1 waves, 128 couts x 64 px
+const CfgEntry kCfgs[] = {
+    // 3x3 + BN + ReLU
+    DCX_CFG(1, 4, 2, 2, 8, 32, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(1, 4, 2, 2, 12, 20, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(1, 4, 2, 2, 6, 40, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(1, 4, 2, 2, 16, 16, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(1, 4, 2, 2, 10, 20, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(2, 2, 2, 2, 6, 18, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(2, 2, 2, 2, 8, 16, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(4, 1, 1, 2, 8, 8, 3, 0, DCX_EPI_BNRELU),
+    // 3x3 + BN + ReLU + 2x2 max-pool
+    DCX_CFG(1, 4, 2, 2, 8, 32, 3, 1, DCX_EPI_BNRELU),
+    DCX_CFG(1, 4, 2, 2, 12, 20, 3, 1, DCX_EPI_BNRELU),
+    DCX_CFG(1, 4, 2, 2, 6, 40, 3, 1, DCX_EPI_BNRELU),
+    DCX_CFG(1, 4, 2, 2, 16, 16, 3, 1, DCX_EPI_BNRELU),
+    DCX_CFG(2, 2, 2, 2, 8, 16, 3, 1, DCX_EPI_BNRELU),
+    // 1x1, raw (image flattened to 1 x P by the caller)
+    DCX_CFG(1, 4, 2, 2, 1, 256, 1, 0, DCX_EPI_RAW),
+    // RefineNet head: 3x3 + BN + ReLU + 1x1 -> 1 channel + tile arg-max
+    DCX_CFG(1, 4, 2, 2, 8, 32, 3, 0, DCX_EPI_HEAT),
+};
+
+const CfgEntry* pick(int ho, int wo, int cout_pad, int ks, int pool, int epi) {
+    const CfgEntry* best = nullptr;
+    double best_score = -1.0;
+    for (const CfgEntry& c : kCfgs) {
+        if (c.ks != ks || c.pool != pool || c.epi != epi) continue;
+        if (cout_pad % c.cout_tile != 0) continue;
+        const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
+        double score = (double)ho * wo / ((double)tiles * c.cap);   // useful fraction of the MFMA work
+        // mild preference for the 64-cout layout (smaller halo re-read per flop) on ties
+        if (c.cout_tile == 64) score += 1e-6;
+        if (score > best_score) { best_score = score; best = &c; }
+    }
+    return best;
+}
+
+// ---- per-launch profiling ---------------------------------------------------------------------
+struct ProfRec { int kernel_id, n, limited; double flops_per_image; hipEvent_t e0, e1; };
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_used = 0;
+
+hipEvent_t prof_event() {
+    if (g_pool_used == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_used++];
+}
+
+}  // namespace
+
+extern "C" int dcx_profile_enable(int enabled) {
+    g_prof = enabled != 0;
+    if (g_prof) { g_recs.clear(); g_pool_used = 0; }
+    return 0;
+}
+extern "C" int dcx_profile_count(void) { return (int)g_recs.size(); }
+extern "C" const char* dcx_profile_kernel_name(int id) {
+    const int n = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+    return id >= 0 && id < n ? kCfgs[id].name : "?";
+}
+extern "C" int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, double* flops_per_image, float* ms,
+                                 int max_records) {
+    if (!kernel_ids || !n_images || !limited || !flops_per_image || !ms) return DCX_E_ARG;
+    int k = 0;
+    for (const ProfRec& r : g_recs) {
+        if (k >= max_records) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) t = -1.f;
+        kernel_ids[k] = r.kernel_id; n_images[k] = r.n; limited[k] = r.limited;
+        flops_per_image[k] = r.flops_per_image; ms[k] = t;
+        ++k;
+    }
+    return k;
+}
+
+// cout <= 64 uses the 64-cout wave layout; anything larger is padded to the 128-cout layouts' multiple.
+int dcx_conv_cout_pad(int cout) { return cout <= 64 ? 64 : (cout + 127) / 128 * 128; }
+
+int dcx_conv_heat_tiles(int ho, int wo) { return ((ho + 7) / 8) * ((wo + 31) / 32); }
+
+int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t stream) {
+    if (a.in == nullptr || a.w == nullptr || a.bias == nullptr) return DCX_E_ARG;
+    if (epi != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
+    if (epi != DCX_EPI_RAW && (a.alpha == nullptr || a.beta == nullptr)) return DCX_E_ARG;
+    if (pool && ((a.ho | a.wo) & 1)) return DCX_E_SHAPE;
+    const CfgEntry* c = pick(a.ho, a.wo, a.cout_pad, ks, pool, epi);
+    if (c == nullptr) return DCX_E_SHAPE;
+    if (!g_prof) return c->launch(a, stream);
+    ProfRec r;
+    r.kernel_id = (int)(c - kCfgs);
+    r.n = a.n;
+    r.limited = a.n_limit != nullptr;
+    r.flops_per_image = 2.0 * a.cout_real * a.cin * ks * ks
+                      * (double)a.ho * a.wo;
+    r.e0 = prof_event();
+    r.e1 = prof_event();
+    if (!r.e0 || !r.e1) return (int)hipErrorOutOfMemory;
+    DCX_CHECK_HIP(hipEventRecord(r.e0, stream));
+    const int rc = c->launch(a, stream);
+    DCX_CHECK_HIP(hipEventRecord(r.e1, stream));
+    if (rc == 0) g_recs.push_back(r);
+    return rc;
+}

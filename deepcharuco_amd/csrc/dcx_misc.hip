@@ -1,0 +1,400 @@
+// dcx_misc.hip -- the HBM-bound kernels around the MFMA convolutions:
+//   * Cin=1 first layers (conv1a of both nets) with the u8 -> f32 normalisation fused in,
+//   * per-cell arg-max + dust-bin mask + 8x8 decode + ordered compaction,
+//   * patch table / 24x24 patch gather / heat-map arg-max finalisation,
+//   * NCHW <-> C4 converters, stand-alone pre_image and argmax2d.
+#include "dcx_common.h"
+
+// pre_bgr_image /root/reference/src/models/model_utils.py:46-50: (float(g) - 128) / 255, IEEE division
+// (hipcc's default f32 division is correctly rounded; tests check all 256 inputs bit-for-bit).
+__device__ __forceinline__ float dcx_norm_u8(uint8_t g) { return ((float)g - 128.0f) / 255.0f; }
+__device__ __forceinline__ float dcx_load_px(const uint8_t* p) { return dcx_norm_u8(*p); }
+__device__ __forceinline__ float dcx_load_px(const float* p) { return *p; }
+
+// ---------------------------------------------------------------------------------------
+// conv1a (+bn1a+relu), Cin = 1 -> 64: net.py:23-24,60 (pad 1) and refinenet.py:21-22,56 (pad 0).
+// One thread = one output pixel, all 64 output channels; acc = fmaf(w[tap], x[tap], acc) for
+// tap = 0..8 (dy-major), then +bias, BN affine, ReLU.  Write-bound: 256 B per pixel, C4 layout,
+// 16-B stores contiguous across lanes.
+template <typename TIn>
+__global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ in, long image_stride, int pitch,
+                                                          int h, int w, int pad,
+                                                          const float* __restrict__ w9x64,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ alpha,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ out, int ho, int wo,
+                                                          const int* __restrict__ n_limit) {
+    __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
+    const int n = blockIdx.y;
+    if (n_limit != nullptr && n >= *n_limit) return;
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) sw[i] = w9x64[i];
+    if (threadIdx.x < 64) {
+        sw[576 + threadIdx.x] = bias[threadIdx.x];
+        sw[640 + threadIdx.x] = alpha[threadIdx.x];
+        sw[704 + threadIdx.x] = beta[threadIdx.x];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= ho * wo) return;
+    const int oy = p / wo, ox = p - oy * wo;
+    const TIn* img = in + (size_t)n * image_stride;
+    float x[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int iy = oy - pad + dy, ix = ox - pad + dx;
+            const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+            const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
+            const float v = dcx_load_px(img + (size_t)cy * pitch + cx);
+            x[dy * 3 + dx] = inb ? v : 0.0f;   // zero padding of the NORMALISED image
+        }
+    float4* out4 = reinterpret_cast<float4*>(out);
+    const float4* sw4 = reinterpret_cast<const float4*>(sw);
+#pragma unroll 4
+    for (int cq = 0; cq < 16; ++cq) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 wv = sw4[t * 16 + cq];
+            acc.x = fmaf(wv.x, x[t], acc.x);
+            acc.y = fmaf(wv.y, x[t], acc.y);
+            acc.z = fmaf(wv.z, x[t], acc.z);
+            acc.w = fmaf(wv.w, x[t], acc.w);
+        }
+        const float4 bi = sw4[144 + cq], al = sw4[160 + cq], be = sw4[176 + cq];
+        float4 y;
+        y.x = fmaxf(fmaf(acc.x + bi.x, al.x, be.x), 0.f);
+        y.y = fmaxf(fmaf(acc.y + bi.y, al.y, be.y), 0.f);
+        y.z = fmaxf(fmaf(acc.z + bi.z, al.z, be.z), 0.f);
+        y.w = fmaxf(fmaf(acc.w + bi.w, al.w, be.w), 0.f);
+        out4[((size_t)n * 16 + cq) * (size_t)(ho * wo) + p] = y;
+    }
+}
+
+template <typename TIn>
+static int launch_conv1(const TIn* in, long image_stride, int pitch, int n, int h, int w, int pad,
+                        const float* w9x64, const float* bias, const float* alpha, const float* beta,
+                        float* out, const int* n_limit, hipStream_t s) {
+    if (!in || !w9x64 || !bias || !alpha || !beta || !out) return DCX_E_ARG;
+    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
+    if (ho <= 0 || wo <= 0 || n <= 0 || n > 65535) return DCX_E_SHAPE;
+    dim3 grid((unsigned)((ho * wo + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL((dcx_conv1_kernel<TIn>), grid, dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
+                       w9x64, bias, alpha, beta, out, ho, wo, n_limit);
+    return (int)hipGetLastError();
+}
+
+int dcx_launch_conv1_u8(const uint8_t* frames, long frame_stride, int pitch, int n, int h, int w, int pad,
+                        const float* w9x64, const float* bias, const float* alpha, const float* beta,
+                        float* out_c4, const int* n_limit, hipStream_t s) {
+    return launch_conv1<uint8_t>(frames, frame_stride, pitch, n, h, w, pad, w9x64, bias, alpha, beta, out_c4, n_limit, s);
+}
+int dcx_launch_conv1_f32(const float* images, long image_stride, int pitch, int n, int h, int w, int pad,
+                         const float* w9x64, const float* bias, const float* alpha, const float* beta,
+                         float* out_c4, const int* n_limit, hipStream_t s) {
+    return launch_conv1<float>(images, image_stride, pitch, n, h, w, pad, w9x64, bias, alpha, beta, out_c4, n_limit, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// pred_argmax (model_utils.py:53-78) + label_to_keypoints (model_utils.py:91-124), batched.
+// One workgroup per frame walks the cells in raster order, 256 at a time; firing cells are
+// compacted in order with wave ballots + an LDS scan, so the row order equals torch.nonzero's.
+__device__ __forceinline__ float dcx_logit(const DcxLogitView& v, int b, int c, int cell) {
+    return v.p[(size_t)b * v.sb + (size_t)(c >> 2) * v.sq + (size_t)cell * v.sp + (size_t)(c & 3) * v.sc];
+}
+
+__global__ __launch_bounds__(256) void dcx_decode_kernel(DcxLogitView loc, DcxLogitView ids, int n_loc, int n_ids1,
+                                                           int hc, int wc, int dust_bin, int kmax,
+                                                           int32_t* __restrict__ counts, int32_t* __restrict__ rows,
+                                                           int32_t* __restrict__ loc_argmax,
+                                                           int32_t* __restrict__ ids_argmax) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cells = hc * wc;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < cells; c0 += 256) {
+        const int cell = c0 + tid;
+        bool fire = false;
+        int la = 0, ia = 0;
+        if (cell < cells) {
+            float best = dcx_logit(loc, b, 0, cell);
+            for (int c = 1; c < n_loc; ++c) {            // torch.argmax: first maximum wins
+                const float v = dcx_logit(loc, b, c, cell);
+                if (v > best) { best = v; la = c; }
+            }
+            best = dcx_logit(ids, b, 0, cell);
+            for (int c = 1; c < n_ids1; ++c) {
+                const float v = dcx_logit(ids, b, c, cell);
+                if (v > best) { best = v; ia = c; }
+            }
+            if (la == n_loc - 1) ia = dust_bin;          // where(loc_argmax == 64, dust_bin, ids_argmax)
+            fire = ia != dust_bin;
+            if (loc_argmax) loc_argmax[(size_t)b * cells + cell] = la;
+            if (ids_argmax) ids_argmax[(size_t)b * cells + cell] = ia;
+        }
+        const unsigned long long m = __ballot(fire);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (fire) {
+            const int pos = off + before;
+            if (pos < kmax) {
+                const int cy = cell / wc, cx = cell - cy * wc;
+                int4 r;
+                r.x = 8 * cx + (la & 7);                  // xs = 8*ix + loc % 8
+                r.y = 8 * cy + (la >> 3);                 // ys = 8*iy + loc // 8
+                r.z = ia;
+                r.w = cell;
+                reinterpret_cast<int4*>(rows)[(size_t)b * kmax + pos] = r;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) base_s += total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[b] = base_s;
+}
+
+int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, int n_ids1, int hc, int wc,
+                      int dust_bin, int kmax, int32_t* counts, int32_t* rows,
+                      int32_t* loc_argmax, int32_t* ids_argmax, hipStream_t s) {
+    if (!loc.p || !ids.p || !counts || !rows) return DCX_E_ARG;
+    if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0 || n_loc != 65 || n_ids1 < 2) return DCX_E_SHAPE;
+    hipLaunchKernelGGL(dcx_decode_kernel, dim3((unsigned)batch), dim3(256), 0, s, loc, ids, n_loc, n_ids1, hc, wc,
+                       dust_bin, kmax, counts, rows, loc_argmax, ids_argmax);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcx_pred_to_keypoints(const float* d_loc, const float* d_ids, int batch, int n_loc, int n_ids1,
+                                     int hc, int wc, int dust_bin, int kmax, int32_t* d_counts, int32_t* d_rows,
+                                     int32_t* d_loc_argmax, int32_t* d_ids_argmax, void* stream) {
+    const long cells = (long)hc * wc;
+    DcxLogitView lv{d_loc, (long)n_loc * cells, 4 * cells, 1, cells};
+    DcxLogitView iv{d_ids, (long)n_ids1 * cells, 4 * cells, 1, cells};
+    return dcx_launch_decode(lv, iv, batch, n_loc, n_ids1, hc, wc, dust_bin, kmax, d_counts, d_rows,
+                             d_loc_argmax, d_ids_argmax, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// patch table: exclusive scan of min(counts, kmax) over the frames of a batch (one workgroup).
+__global__ __launch_bounds__(256) void dcx_patch_table_kernel(const int32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ rows, int batch, int kmax,
+                                                                int32_t* __restrict__ table, int32_t* __restrict__ total) {
+    __shared__ int sc[256];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < batch; b0 += 256) {
+        const int b = b0 + tid;
+        const int c = b < batch ? min(counts[b], kmax) : 0;
+        sc[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {      // Hillis-Steele inclusive scan
+            const int v = tid >= d ? sc[tid - d] : 0;
+            __syncthreads();
+            sc[tid] += v;
+            __syncthreads();
+        }
+        const int start = carry + sc[tid] - c;
+        for (int k = 0; k < c; ++k) {
+            const int4 r = reinterpret_cast<const int4*>(rows)[(size_t)b * kmax + k];
+            reinterpret_cast<int4*>(table)[start + k] = make_int4(b, r.x, r.y, b * kmax + k);
+        }
+        __syncthreads();
+        if (tid == 255) carry += sc[255];
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
+}
+
+extern "C" int dcx_build_patch_table(const int32_t* d_counts, const int32_t* d_rows, int batch, int kmax,
+                                     int32_t* d_table, int32_t* d_total, void* stream) {
+    if (!d_counts || !d_rows || !d_table || !d_total) return DCX_E_ARG;
+    if (batch <= 0 || kmax <= 0) return DCX_E_SHAPE;
+    hipLaunchKernelGGL(dcx_patch_table_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_counts, d_rows, batch,
+                       kmax, d_table, d_total);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// extract_patches model_utils.py:19-36: patch[p][i][j] = img[y-12+i][x-12+j], zero outside.
+template <typename TIn>
+__global__ __launch_bounds__(192) void dcx_gather_kernel(const TIn* __restrict__ frames, long frame_stride, int pitch,
+                                                           int h, int w, const int32_t* __restrict__ table,
+                                                           const int32_t* __restrict__ total,
+                                                           float* __restrict__ patches) {
+    const int p = blockIdx.x;
+    if (total != nullptr && p >= *total) return;
+    const int4 t = reinterpret_cast<const int4*>(table)[p];
+    const TIn* img = frames + (size_t)t.x * frame_stride;
+    for (int e = threadIdx.x; e < 576; e += 192) {
+        const int i = e / 24, j = e - i * 24;
+        const int iy = t.z - 12 + i, ix = t.y - 12 + j;
+        const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+        const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
+        const float v = dcx_load_px(img + (size_t)cy * pitch + cx);
+        patches[(size_t)p * 576 + e] = inb ? v : 0.0f;
+    }
+}
+
+extern "C" int dcx_extract_patches_u8(const uint8_t* d_frames, long frame_stride, int pitch, int height, int width,
+                                      const int32_t* d_table, const int32_t* d_total, int max_patches,
+                                      float* d_patches, void* stream) {
+    if (!d_frames || !d_table || !d_patches) return DCX_E_ARG;
+    if (max_patches <= 0 || height <= 0 || width <= 0) return DCX_E_SHAPE;
+    hipLaunchKernelGGL((dcx_gather_kernel<uint8_t>), dim3((unsigned)max_patches), dim3(192), 0, (hipStream_t)stream,
+                       d_frames, frame_stride, pitch, height, width, d_table, d_total, d_patches);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcx_extract_patches_f32(const float* d_images, int height, int width, const int32_t* d_table,
+                                       const int32_t* d_total, int max_patches, float* d_patches, void* stream) {
+    if (!d_images || !d_table || !d_patches) return DCX_E_ARG;
+    if (max_patches <= 0 || height <= 0 || width <= 0) return DCX_E_SHAPE;
+    hipLaunchKernelGGL((dcx_gather_kernel<float>), dim3((unsigned)max_patches), dim3(192), 0, (hipStream_t)stream,
+                       d_images, (long)height * width, width, height, width, d_table, d_total, d_patches);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// RefineNet.infer_patches refinenet.py:108-114: reduce the per-tile maxima of the heat-map to the
+// first flat arg-max, corners = (col,row), corners_og = (corners - 32) / 8 + keypoint.
+__global__ __launch_bounds__(64) void dcx_refine_finalize_kernel(const float* __restrict__ part_val,
+                                                                   const int* __restrict__ part_idx, int tiles, int wo,
+                                                                   int max_patches, const int* __restrict__ total,
+                                                                   const int32_t* __restrict__ table,
+                                                                   int32_t* __restrict__ corners,
+                                                                   float* __restrict__ xy) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= max_patches) return;
+    if (total != nullptr && p >= *total) return;
+    float best = part_val[(size_t)p * tiles];
+    int besti = part_idx[(size_t)p * tiles];
+    for (int t = 1; t < tiles; ++t) {
+        const float v = part_val[(size_t)p * tiles + t];
+        const int i = part_idx[(size_t)p * tiles + t];
+        if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+    }
+    const int row = besti / wo, col = besti - row * wo;
+    if (corners) { corners[2 * p] = col; corners[2 * p + 1] = row; }
+    if (xy != nullptr && table != nullptr) {
+        const int4 t = reinterpret_cast<const int4*>(table)[p];
+        xy[2 * (size_t)t.w] = (float)(col - 32) / 8.0f + (float)t.y;
+        xy[2 * (size_t)t.w + 1] = (float)(row - 32) / 8.0f + (float)t.z;
+    }
+}
+
+int dcx_launch_refine_finalize(const float* part_val, const int* part_idx, int tiles, int wo, int max_patches,
+                               const int* total, const int32_t* table, int32_t* corners, float* xy, hipStream_t s) {
+    hipLaunchKernelGGL(dcx_refine_finalize_kernel, dim3((unsigned)((max_patches + 63) / 64)), dim3(64), 0, s, part_val,
+                       part_idx, tiles, wo, max_patches, total, table, corners, xy);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// speedy_bargmax2d model_utils.py:39-43 for arbitrary (K,h,w): first flat maximum -> (col,row).
+__global__ __launch_bounds__(256) void dcx_argmax2d_kernel(const float* __restrict__ x, int hw, int w,
+                                                             int32_t* __restrict__ out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = x + (size_t)k * hw;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int i = tid; i < hw; i += 256) {
+        const float v = p[i];
+        if (v > best) { best = v; besti = i; }   // i increases per thread: first max kept
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(besti, off);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int wv = 1; wv < 4; ++wv)
+            if (sv[wv] > best || (sv[wv] == best && si[wv] < besti)) { best = sv[wv]; besti = si[wv]; }
+        if (besti == 0x7fffffff) besti = 0;
+        out[2 * k] = besti % w;
+        out[2 * k + 1] = besti / w;
+    }
+}
+
+extern "C" int dcx_argmax2d(const float* d_x, int k, int h, int w, int32_t* d_out, void* stream) {
+    if (!d_x || !d_out) return DCX_E_ARG;
+    if (k <= 0 || h <= 0 || w <= 0) return DCX_E_SHAPE;
+    hipLaunchKernelGGL(dcx_argmax2d_kernel, dim3((unsigned)k), dim3(256), 0, (hipStream_t)stream, d_x, h * w, w, d_out);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dcx_pre_image_kernel(const uint8_t* __restrict__ g, float* __restrict__ out,
+                                                              size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = dcx_norm_u8(g[i]);
+}
+
+extern "C" int dcx_pre_image(const uint8_t* d_gray, float* d_out, size_t n, void* stream) {
+    if (!d_gray || !d_out) return DCX_E_ARG;
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dcx_pre_image_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_gray, d_out, n);
+    return (int)hipGetLastError();
+}
+
+// NCHW [n][c][hw] <-> C4 [n][ceil(c/4)][hw][4]
+__global__ __launch_bounds__(256) void dcx_nchw_to_c4_kernel(const float* __restrict__ src, int c, int hw,
+                                                               float* __restrict__ dst) {
+    const int cq_n = (c + 3) >> 2;
+    const int n = blockIdx.z, cq = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* s = src + ((size_t)n * c + 4 * cq) * hw + p;
+    if (4 * cq + 0 < c) v.x = s[0];
+    if (4 * cq + 1 < c) v.y = s[(size_t)hw];
+    if (4 * cq + 2 < c) v.z = s[2 * (size_t)hw];
+    if (4 * cq + 3 < c) v.w = s[3 * (size_t)hw];
+    reinterpret_cast<float4*>(dst)[((size_t)n * cq_n + cq) * hw + p] = v;
+}
+
+__global__ __launch_bounds__(256) void dcx_c4_to_nchw_kernel(const float* __restrict__ src, int c, int hw,
+                                                               float* __restrict__ dst) {
+    const int cq_n = (c + 3) >> 2;
+    const int n = blockIdx.z, cq = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const float4 v = reinterpret_cast<const float4*>(src)[((size_t)n * cq_n + cq) * hw + p];
+    float* d = dst + ((size_t)n * c + 4 * cq) * hw + p;
+    if (4 * cq + 0 < c) d[0] = v.x;
+    if (4 * cq + 1 < c) d[(size_t)hw] = v.y;
+    if (4 * cq + 2 < c) d[2 * (size_t)hw] = v.z;
+    if (4 * cq + 3 < c) d[3 * (size_t)hw] = v.w;
+}
+
+extern "C" int dcx_nchw_to_c4(const float* d_nchw, int n, int c, int h, int w, float* d_c4, void* stream) {
+    if (!d_nchw || !d_c4) return DCX_E_ARG;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || n > 65535) return DCX_E_SHAPE;
+    dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)((c + 3) / 4), (unsigned)n);
+    hipLaunchKernelGGL(dcx_nchw_to_c4_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_nchw, c, h * w, d_c4);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dcx_c4_to_nchw(const float* d_c4, int n, int c, int h, int w, float* d_nchw, void* stream) {
+    if (!d_nchw || !d_c4) return DCX_E_ARG;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || n > 65535) return DCX_E_SHAPE;
+    dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)((c + 3) / 4), (unsigned)n);
+    hipLaunchKernelGGL(dcx_c4_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_c4, c, h * w, d_nchw);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,218 @@
+"""Drop-in for /root/reference/src/inference.py: ``load_models`` (:73-84), ``infer_image`` (:32-70),
+``solve_pnp`` (:15-29) with the reference's signatures, plus the batched ``infer_batch``.
+
+``infer_image`` runs the library's sync-free batch pipeline with B = 1 (one H2D of the gray frame,
+one D2H of the packed corner list).  ``infer_image_staged`` follows the reference statement by
+statement through the mirrored ``models.*`` functions (same intermediate tensors, same host syncs)
+and exists so every mirrored function is exercised end to end; both return identical arrays.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .imgproc import bgr2gray
+from .models._handles import Workspace, require_cuda
+from .models.model_utils import extract_patches, pre_bgr_image, pred_to_keypoints
+from .models.net import dcModel, lModel
+from .models.refinenet import RefineNet, lRefineNet
+
+__all__ = ["load_models", "infer_image", "infer_image_staged", "infer_batch", "infer_batch_device",
+           "solve_pnp", "InferenceModel"]
+
+DEFAULT_KMAX = 64
+
+
+def load_models(deepc_ckpt: str, refinenet_ckpt: Optional[str] = None, n_ids: int = 16, device="cuda"):
+    """inference.py:73-84: checkpoints -> (deepc, refinenet | None), weights resident on ``device``."""
+    deepc = lModel.load_from_checkpoint(deepc_ckpt, dcModel=dcModel(n_ids))
+    deepc.eval()
+    deepc.to(device)
+    refinenet = None
+    if refinenet_ckpt is not None:
+        refinenet = lRefineNet.load_from_checkpoint(refinenet_ckpt, refinenet=RefineNet())
+        refinenet.eval()
+        refinenet.to(device)
+    return deepc, refinenet
+
+
+def solve_pnp(keypoints, col_count, row_count, square_len, camera_matrix, dist_coeffs):
+    """inference.py:15-29. Host side (cv2.solvePnP), as in the reference."""
+    if keypoints.shape[0] < 4:
+        return False, None, None
+    inn_rc = np.arange(1, row_count)
+    inn_cc = np.arange(1, col_count)
+    object_points = np.zeros(((col_count - 1) * (row_count - 1), 3), np.float32)
+    object_points[:, :2] = np.array(np.meshgrid(inn_rc, inn_cc)).reshape((2, -1)).T * square_len
+    image_points = keypoints[:, :2].astype(np.float32)
+    object_points_found = object_points[keypoints[:, 2].astype(int)]
+    try:
+        import cv2  # type: ignore
+    except ImportError as e:  # pragma: no cover - cv2 is absent in the build image
+        raise ImportError("solve_pnp needs OpenCV (cv2.solvePnP), which is not installed") from e
+    return cv2.solvePnP(object_points_found, image_points, camera_matrix, dist_coeffs)
+
+
+# ------------------------------------------------------------------------------------------------
+
+def _unwrap(deepc, refinenet):
+    det = deepc.model if hasattr(deepc, "model") else deepc
+    ref = None
+    if refinenet is not None:
+        ref = refinenet.model if hasattr(refinenet, "model") else refinenet
+    return det, ref
+
+
+_ws = Workspace()
+
+
+def infer_batch_device(frames: torch.Tensor, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Enqueue detect+refine for a batch of GPU-resident gray frames; no host synchronisation.
+
+    frames: (B,H,W) uint8 on the GPU.  Returns the packed result tensor (int32, on the GPU):
+    ``out[b, 0, 0]`` = number of firing cells of frame b, ``out[b, 1+k]`` = (x, y, id, cell) of the
+    k-th corner in raster order followed by (x_refined, y_refined) as float32 bit patterns:
+    shape (B, 1 + kmax, 6).  Rows k >= count are unspecified.  Use ``unpack_results`` on the host.
+    """
+    det, ref = _unwrap(deepc, refinenet)
+    dev = det.device
+    if frames.device != dev or frames.dtype != torch.uint8 or frames.ndim != 3 or not frames.is_contiguous():
+        raise ValueError("frames must be a contiguous (B,H,W) uint8 tensor on the model's GPU")
+    b, h, w = frames.shape
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        nbytes = L.dcx_pipeline_workspace_bytes(det.handle, ref.handle if ref else None, b, h, w, kmax)
+        if nbytes == 0:
+            raise ValueError("bad batch/shape for dcx_pipeline_workspace_bytes")
+        ws = _ws.get("pipe", dev, nbytes)
+        # outputs: counts [B] | rows [B,kmax,4] | xy [B,kmax,2], one allocation so one D2H moves all
+        n_i32 = b + b * kmax * 4 + b * kmax * 2
+        if out is None or out.numel() != n_i32:
+            out = torch.empty((n_i32,), dtype=torch.int32, device=dev)
+        base = out.data_ptr()
+        counts_p, rows_p, xy_p = base, base + 4 * b, base + 4 * (b + b * kmax * 4)
+        _lib.check(L.dcx_infer_batch(det.handle, ref.handle if ref else None, frames.data_ptr(), h * w, w, b, h, w,
+                                     dust_bin_ids, kmax, ws.data_ptr(), ws.numel(), counts_p, rows_p,
+                                     xy_p if ref else None, _lib.current_stream()), "dcx_infer_batch")
+    return out
+
+
+def unpack_results(packed: np.ndarray, batch: int, kmax: int, refined: bool) -> Tuple[List[np.ndarray], np.ndarray]:
+    """Host unpack of ``infer_batch_device``'s buffer -> per-frame arrays in infer_image's format.
+
+    Per frame: (K,3) rows [x, y, id] sorted by id (stable w.r.t. raster order, inference.py:68-69);
+    float64 when refined, int64 otherwise; ``np.array([])`` when K == 0 (inference.py:51-52).
+    Also returns the raw counts (counts[b] > kmax means frame b overflowed the capacity).
+    """
+    packed = np.asarray(packed, dtype=np.int32)
+    counts = packed[:batch]
+    rows = packed[batch:batch + batch * kmax * 4].reshape(batch, kmax, 4)
+    xy = packed[batch + batch * kmax * 4:].view(np.float32).reshape(batch, kmax, 2)
+    res: List[np.ndarray] = []
+    for b in range(batch):
+        k = int(min(counts[b], kmax))
+        if k == 0:
+            res.append(np.array([]))
+            continue
+        ids = rows[b, :k, 2].astype(np.int64)
+        order = np.argsort(ids, kind="stable")
+        if refined:
+            a = np.empty((k, 3), np.float64)
+            a[:, 0:2] = xy[b, :k].astype(np.float64)
+        else:
+            a = np.empty((k, 3), np.int64)
+            a[:, 0:2] = rows[b, :k, 0:2]
+        a[:, 2] = ids
+        res.append(a[order])
+    return res, counts.copy()
+
+
+def infer_batch(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX):
+    """Batched infer_image: frames_gray (B,H,W) uint8 host array -> list of B keypoint arrays.
+
+    Frames are independent (the reference has no cross-frame state), so frame b's result equals
+    ``infer_image`` on that frame alone.  If a frame fires more than ``kmax`` cells the batch is
+    re-run with a larger capacity (never silently truncated).
+    """
+    det, _ = _unwrap(deepc, refinenet)
+    dev = det.device
+    frames_gray = np.ascontiguousarray(frames_gray, dtype=np.uint8)
+    if frames_gray.ndim != 3:
+        raise ValueError("expected (B,H,W) uint8 gray frames")
+    b, h, w = frames_gray.shape
+    cells = (h // 8) * (w // 8)
+    d_frames = torch.from_numpy(frames_gray).to(dev)
+    while True:
+        packed = infer_batch_device(d_frames, dust_bin_ids, deepc, refinenet, kmax).cpu().numpy()
+        res, counts = unpack_results(packed, b, kmax, refinenet is not None)
+        if int(counts.max()) <= kmax:
+            return res
+        new_kmax = min(cells, max(2 * kmax, int(counts.max())))
+        warnings.warn(f"a frame produced {int(counts.max())} corners > kmax={kmax}; re-running with kmax={new_kmax}")
+        kmax = new_kmax
+
+
+def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_pred: bool = False, device="cuda"):
+    """inference.py:32-70. BGR uint8 (H,W,3) -> (keypoints (K,3) [x,y,id] sorted by id, image)."""
+    require_cuda(device)
+    img_gray = bgr2gray(img)
+    keypoints = infer_batch(img_gray[None], dust_bin_ids, deepc, refinenet)[0]
+    if draw_pred:
+        img = _draw(img, keypoints, refined=refinenet is not None)
+    return keypoints, img
+
+
+def infer_image_staged(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_pred: bool = False,
+                       device="cuda"):
+    """The reference's body (inference.py:40-70) statement by statement on the mirrored functions."""
+    require_cuda(device)
+    img_gray = bgr2gray(img)
+    img_gray = pre_bgr_image(img_gray)
+    img_gray = torch.tensor(img_gray, device=device)
+    loc_hat, ids_hat = deepc.infer_image(img_gray)
+    keypoints, ids_found = pred_to_keypoints(loc_hat, ids_hat, dust_bin_ids)
+    if ids_found.shape[0] == 0:
+        return np.array([]), img
+    if refinenet is not None:
+        patches = extract_patches(img_gray, keypoints)
+        keypoints, _ = refinenet.infer_patches(patches, keypoints)
+    keypoints = keypoints.cpu().numpy()
+    ids_found = ids_found.cpu().numpy()
+    keypoints = np.array([[k[0], k[1], idx] for k, idx in sorted(zip(keypoints, ids_found), key=lambda x: x[1])])
+    if draw_pred:
+        img = _draw(img, keypoints, refined=refinenet is not None)
+    return keypoints, img
+
+
+def _draw(img: np.ndarray, keypoints: np.ndarray, refined: bool) -> np.ndarray:
+    """Minimal stand-in for aruco_utils.draw_inner_corners (:135-192): circles + ids on a COPY."""
+    try:
+        import cv2  # type: ignore
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("draw_pred=True needs OpenCV for drawing, which is not installed") from e
+    out = img.copy()
+    for x, y, idx in np.asarray(keypoints).reshape(-1, 3):
+        c = (int(round(float(x))), int(round(float(y))))
+        cv2.circle(out, c, 1 if refined else 3, (0, 255, 255) if refined else (0, 0, 255), -1)
+        cv2.putText(out, str(int(idx)), c, cv2.FONT_HERSHEY_SIMPLEX, 0.3, (0, 0, 255), 1)
+    return out
+
+
+class InferenceModel:
+    """Convenience holder (the north-star's "InferenceModel"): both nets + device, reference call shapes."""
+
+    def __init__(self, deepc_ckpt: str, refinenet_ckpt: Optional[str] = None, n_ids: int = 16, device="cuda"):
+        self.n_ids = n_ids
+        self.device = device
+        self.deepc, self.refinenet = load_models(deepc_ckpt, refinenet_ckpt, n_ids, device)
+
+    def infer_image(self, img: np.ndarray, draw_pred: bool = False):
+        return infer_image(img, self.n_ids, self.deepc, self.refinenet, draw_pred, self.device)
+
+    def infer_batch(self, frames_gray: np.ndarray, kmax: int = DEFAULT_KMAX):
+        return infer_batch(frames_gray, self.n_ids, self.deepc, self.refinenet, kmax)

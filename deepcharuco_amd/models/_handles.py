@@ -1,0 +1,59 @@
+"""Shared plumbing for the model mirrors: device checks, handle creation, workspace cache."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..weights import StateDict, state_dict_keys, validate_state_dict
+
+
+def require_cuda(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"deepcharuco_amd runs on MI355X (device 'cuda'); got device={device!r}. "
+            "There is no CPU fallback -- use the reference implementation on CPU.")
+    if not torch.cuda.is_available():
+        raise RuntimeError("deepcharuco_amd needs a visible ROCm GPU (torch.cuda.is_available() is False)")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def tensor_pointer_array(sd: StateDict, kind: str, n_ids: int):
+    """Host float32 arrays in state_dict_keys() order -> (ctypes void* array, keep-alive list)."""
+    validate_state_dict(sd, kind, n_ids)
+    keep = [np.ascontiguousarray(sd[k], dtype=np.float32) for k in state_dict_keys(kind, n_ids)]
+    arr = (C.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
+    return arr, keep
+
+
+class Workspace:
+    """Grow-only device scratch buffer (a torch uint8 tensor) per device."""
+
+    def __init__(self):
+        self._buf: Dict[Tuple[str, int], torch.Tensor] = {}
+
+    def get(self, tag: str, device: torch.device, nbytes: int) -> torch.Tensor:
+        key = (tag, device.index)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            self._buf.pop(key, None)
+            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+def check_dev_tensor(t: torch.Tensor, device: torch.device, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); deepcharuco_amd has no CPU path")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()

@@ -1,0 +1,180 @@
+/*
+ * deepcharuco_amd.h -- C ABI of libdeepcharuco_amd.so (MI355X / gfx950 only).
+ *
+ * The reference (JunkyByte/deepcharuco) has no FFI: its boundary is the Python
+ * function API of src/inference.py.  This header is what a binding for that
+ * path links against; deepcharuco_amd/_lib.py binds it with ctypes and
+ * deepcharuco_amd/inference.py rebuilds the reference's Python API on top
+ * (see INTEGRATION.md).  Each entry point cites the reference interface it
+ * replaces (paths relative to /root/reference/src).
+ *
+ * Conventions
+ *   - every `d_` pointer is a DEVICE pointer owned by the caller (e.g. a
+ *     torch tensor's data_ptr()); every `h_` pointer is host memory;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no
+ *     entry point synchronises the device or allocates after create();
+ *   - return value: 0 ok, <0 argument/shape error (DCX_E_*), >0 hipError_t;
+ *   - no C++ exception crosses the boundary; handles are not thread-safe
+ *     (use one handle per stream);
+ *   - activations inside the library use the "C4" layout
+ *     [N][C/4][H][W][4] float32 (channel-quad planar); NCHW only at the API.
+ */
+#ifndef DEEPCHARUCO_AMD_H
+#define DEEPCHARUCO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCX_E_ARG      (-1)   /* null pointer / bad scalar */
+#define DCX_E_SHAPE    (-2)   /* H or W not a multiple of 8, patch not 24x24 ... */
+#define DCX_E_WS       (-3)   /* workspace too small */
+#define DCX_E_NIDS     (-4)   /* dust_bin / n_ids mismatch */
+
+typedef struct dcx_detector dcx_detector;   /* dcModel  (models/net.py:9-99)        */
+typedef struct dcx_refiner  dcx_refiner;    /* RefineNet (models/refinenet.py:9-115) */
+
+const char* dcx_version(void);
+/* human readable text for a return code (static storage) */
+const char* dcx_error_string(int code);
+
+/* ---- model lifetime: replaces load_models() inference.py:73-84 ----------------------
+ * h_tensors: host float32 arrays in the order deepcharuco_amd.weights.state_dict_keys()
+ * gives, i.e. for every conv in forward order: weight (OIHW), bias and -- where a
+ * BatchNorm2d follows -- gamma, beta, running_mean, running_var.  The library packs the
+ * weights into its MFMA operand layout, folds eval-mode BN (eps 1e-5) into a per-channel
+ * (alpha, beta') pair exactly as ATen's CPU inference path does, and uploads them.
+ * Detector: 12 convs / 10 BN = 64 tensors; RefineNet: 12 convs / 11 BN = 68 tensors.   */
+int dcx_detector_create(dcx_detector** out, const float* const* h_tensors, int n_tensors, int n_ids);
+int dcx_detector_destroy(dcx_detector* det);
+int dcx_refiner_create(dcx_refiner** out, const float* const* h_tensors, int n_tensors);
+int dcx_refiner_destroy(dcx_refiner* rf);
+
+/* ---- workspace sizing (bytes of device scratch the forward calls need) -------------- */
+size_t dcx_detector_workspace_bytes(const dcx_detector* det, int batch, int height, int width);
+size_t dcx_refiner_workspace_bytes(const dcx_refiner* rf, int max_patches);
+
+/* ---- pre-processing ------------------------------------------------------------------
+ * pre_bgr_image models/model_utils.py:46-50:  out = (float(g) - 128) / 255 (IEEE division).
+ * d_gray [n] u8 -> d_out [n] f32.                                                        */
+int dcx_pre_image(const uint8_t* d_gray, float* d_out, size_t n, void* stream);
+
+/* ---- detector forward: dcModel.forward net.py:50-80 / infer_image net.py:82-99 -------
+ * Input either u8 gray frames (d_frames_u8, row pitch in bytes, frame stride in bytes;
+ * normalised on the fly exactly like dcx_pre_image) or already-normalised f32 images
+ * (d_images_f32, dense [B][H][W]); exactly one of the two must be non-null.
+ * Outputs (either may be null): logits in NCHW, loc [B][65][H/8][W/8], ids [B][n_ids+1][H/8][W/8].
+ * The C4 logits stay in the workspace for dcx_detector_decode().                          */
+int dcx_detector_forward(const dcx_detector* det,
+                         const uint8_t* d_frames_u8, long frame_stride, int pitch,
+                         const float* d_images_f32,
+                         int batch, int height, int width,
+                         void* d_ws, size_t ws_bytes,
+                         float* d_loc_nchw, float* d_ids_nchw, void* stream);
+
+/* ---- decode: pred_to_keypoints model_utils.py:81-88 (= pred_argmax :53-78 +
+ *      label_to_keypoints :91-124), batched -----------------------------------------------
+ * Per cell: loc = argmax_c loc_logits (first max), id = argmax_c ids_logits, id = dust_bin
+ * where loc == 64; cells with id != dust_bin emit a row {x = 8*cx + loc%8, y = 8*cy + loc/8,
+ * id, cell = cy*Wc + cx} in raster order per frame.  d_counts[b] = number of firing cells
+ * (may exceed kmax; only the first kmax rows are stored).  d_rows: int32 [B][kmax][4].
+ * Optional dense maps d_loc_argmax / d_ids_argmax: int32 [B][Hc][Wc] (ids map is post-mask).
+ * dcx_detector_decode reads the logits the preceding dcx_detector_forward left in d_ws;
+ * dcx_pred_to_keypoints takes caller NCHW logits (the reference's own signature).        */
+int dcx_detector_decode(const dcx_detector* det, int batch, int height, int width,
+                        const void* d_ws, int dust_bin, int kmax,
+                        int32_t* d_counts, int32_t* d_rows,
+                        int32_t* d_loc_argmax, int32_t* d_ids_argmax, void* stream);
+int dcx_pred_to_keypoints(const float* d_loc_nchw, const float* d_ids_nchw,
+                          int batch, int n_loc, int n_ids1, int hc, int wc,
+                          int dust_bin, int kmax,
+                          int32_t* d_counts, int32_t* d_rows,
+                          int32_t* d_loc_argmax, int32_t* d_ids_argmax, void* stream);
+
+/* ---- patch table: compacts the per-frame rows of a batch into one patch list ----------
+ * d_table int32 [B*kmax][4] = {frame, x, y, slot = frame*kmax + k}; d_total int32 [1] =
+ * sum_b min(counts[b], kmax).  Device-side replacement for the host syncs at
+ * model_utils.py:114 / inference.py:51.                                                  */
+int dcx_build_patch_table(const int32_t* d_counts, const int32_t* d_rows, int batch, int kmax,
+                          int32_t* d_table, int32_t* d_total, void* stream);
+
+/* ---- extract_patches models/model_utils.py:19-36 ---------------------------------------
+ * patch[p][i][j] = img[y-12+i][x-12+j], 0.0f outside the image (zero pad of the NORMALISED
+ * image).  d_table rows {frame,x,y,slot}; patches beyond *d_total (if non-null) are skipped.
+ * u8 variant normalises on the fly; f32 variant takes dense normalised images [B][H][W].   */
+int dcx_extract_patches_u8(const uint8_t* d_frames, long frame_stride, int pitch, int height, int width,
+                           const int32_t* d_table, const int32_t* d_total, int max_patches,
+                           float* d_patches, void* stream);
+int dcx_extract_patches_f32(const float* d_images, int height, int width,
+                            const int32_t* d_table, const int32_t* d_total, int max_patches,
+                            float* d_patches, void* stream);
+
+/* ---- RefineNet: forward refinenet.py:49-83 + infer_patches :85-115 ---------------------
+ * d_patches f32 [P][24][24] -> per patch flat argmax (first max) of the 64x64 heat-map:
+ * d_corners int32 [P][2] = {col,row}; if d_table/d_xy given, d_xy[slot] = {(col-32)/8 + x,
+ * (row-32)/8 + y} (float32, refinenet.py:114).  d_heat (nullable) f32 [P][64][64] receives
+ * the raw heat-map.  Patches >= *d_total (if non-null) are skipped.                       */
+int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches, int max_patches,
+                        const int32_t* d_total, const int32_t* d_table,
+                        void* d_ws, size_t ws_bytes,
+                        int32_t* d_corners, float* d_xy, float* d_heat, void* stream);
+
+/* ---- speedy_bargmax2d models/model_utils.py:39-43 --------------------------------------
+ * d_x f32 [K][h][w] -> d_out int32 [K][2] = {col,row} of the first maximum.               */
+int dcx_argmax2d(const float* d_x, int k, int h, int w, int32_t* d_out, void* stream);
+
+/* ---- whole path for a batch: infer_image inference.py:32-70 without host syncs ----------
+ * frames u8 -> rows/counts (detector+decode) -> patch table -> patches -> RefineNet -> xy.
+ * d_xy f32 [B][kmax][2]; rows beyond counts[b] are untouched.  d_ws must hold
+ * dcx_pipeline_workspace_bytes().  rf may be null (detector only; d_xy ignored).          */
+size_t dcx_pipeline_workspace_bytes(const dcx_detector* det, const dcx_refiner* rf,
+                                    int batch, int height, int width, int kmax);
+int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf,
+                    const uint8_t* d_frames_u8, long frame_stride, int pitch,
+                    int batch, int height, int width, int dust_bin, int kmax,
+                    void* d_ws, size_t ws_bytes,
+                    int32_t* d_counts, int32_t* d_rows, float* d_xy, void* stream);
+
+/* ---- stage-level entry point for kernel tests / roofline measurement -------------------
+ * One 3x3 (or 1x1) convolution + bias [+ eval-BN + ReLU] [+ 2x2 max-pool] on C4 tensors
+ * using the same MFMA kernel the networks use.  h_* are host arrays in PyTorch layout;
+ * the call packs/uploads them (synchronously) and then enqueues the kernel on `stream`.
+ * ups: input is read through a nearest x2 up-sampling.  d_in C4 [N][cin/4][Hin][Win][4],
+ * d_out C4 [N][ceil(cout/4)][Hout][Wout][4].                                              */
+int dcx_conv_layer(const float* d_in, int n, int cin, int hin, int win,
+                   const float* h_weight_oihw, const float* h_bias,
+                   const float* h_bn_gamma, const float* h_bn_beta,
+                   const float* h_bn_mean, const float* h_bn_var,
+                   int cout, int ksize, int pad, int ups, int pool, int relu,
+                   float* d_out, void* stream);
+/* NCHW <-> C4 layout converters (tests, API edges). c need not be a multiple of 4 (zero fill). */
+int dcx_nchw_to_c4(const float* d_nchw, int n, int c, int h, int w, float* d_c4, void* stream);
+int dcx_c4_to_nchw(const float* d_c4, int n, int c, int h, int w, float* d_nchw, void* stream);
+
+/* ---- instrumentation: per-stage device time of the last dcx_infer_batch() ---------------
+ * When enabled, the pipeline records hipEvents on its stream around each stage; after the
+ * stream has been synchronised by the caller, dcx_last_timings() returns milliseconds:
+ * [0] detector conv stack, [1] decode+table+gather, [2] RefineNet, [3] total.              */
+int dcx_set_timing(int enabled);
+int dcx_last_timings(float* h_ms4);
+
+/* ---- instrumentation: per-launch profile of the MFMA convolution kernel (roofline) ---------
+ * While enabled, every launch of the convolution kernel is bracketed by two hipEvents on its
+ * stream and recorded.  dcx_profile_enable(1) clears the record list.  After the caller has
+ * synchronised the stream(s), dcx_profile_fetch() returns up to max_records records:
+ * kernel_ids[i] (index into the instantiation table, see dcx_profile_kernel_name), n_images[i]
+ * (images the grid covered), limited[i] (1 if a device-side patch count may have skipped some
+ * of them), flops_per_image[i] = 2*cout*cin*ks*ks*Ho*Wo (algorithmic, un-padded), ms[i].      */
+int dcx_profile_enable(int enabled);
+int dcx_profile_count(void);
+int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, double* flops_per_image, float* ms,
+                      int max_records);
+const char* dcx_profile_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPCHARUCO_AMD_H */

@@ -1,0 +1,69 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+CASES = ["tiny_noise_64x96", "noise_240x320", "board_240x320", "board_480x640"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) when no GPU is visible, e.g. `pytest tests` in the build container
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+class GoldenCase:
+    """A fixture file + the regenerated (SHA-checked) weights and frame it was produced from."""
+
+    def __init__(self, name):
+        from deepcharuco_amd import weights as W
+        self.name = name
+        self.fx = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+        self.meta = json.loads(str(self.fx["meta"]))
+        m = self.meta
+        self.n_ids = m["n_ids"]
+        self.sd_dc = W.synthetic_state_dict("detector", m["wseed"], m["n_ids"])
+        self.sd_dc["convDb.bias"][m["n_ids"]] = self.fx["dust_bias"]
+        self.sd_rn = W.synthetic_state_dict("refinenet", m["wseed"] + 1)
+        self.frame = W.synthetic_frames(m["kind"], m["fseed"], 1, m["H"], m["W"])[0]
+        assert W.state_dict_sha256(self.sd_dc, "detector", m["n_ids"]) == str(self.fx["sha_dc"]), \
+            "regenerated detector weights differ from the ones the fixture was made with"
+        assert W.state_dict_sha256(self.sd_rn, "refinenet") == str(self.fx["sha_rn"])
+        assert W.frames_sha256(self.frame) == str(self.fx["sha_frame"])
+
+    @property
+    def bgr(self):
+        return np.repeat(self.frame[..., None], 3, axis=2)
+
+
+_cache = {}
+
+
+@pytest.fixture(params=CASES)
+def golden(request):
+    if request.param not in _cache:
+        _cache[request.param] = GoldenCase(request.param)
+    return _cache[request.param]
+
+
+@pytest.fixture
+def golden_tiny():
+    if "tiny_noise_64x96" not in _cache:
+        _cache["tiny_noise_64x96"] = GoldenCase("tiny_noise_64x96")
+    return _cache["tiny_noise_64x96"]
