@@ -291,14 +291,15 @@ def test_infer_image_vs_golden(dev, golden):
     from deepcharuco_amd.inference import infer_image, infer_image_staged
     fx = golden.fx
     dc, rn = _models(golden, dev)
+    bgr = golden.bgr
     for fn in (infer_image, infer_image_staged):
-        kp, img = fn(golden.bgr, golden.n_ids, dc, rn, draw_pred=False, device="cuda")
-        assert img is golden.bgr
+        kp, img = fn(bgr, golden.n_ids, dc, rn, draw_pred=False, device="cuda")
+        assert img is bgr                                                       # same object when not drawing
         assert kp.dtype == np.float64 and kp.shape == fx["final_rn"].shape
         assert np.array_equal(kp[:, 2], fx["final_rn"][:, 2])                  # corner ids: exact
         assert np.abs(kp[:, :2] - fx["final_rn"][:, :2]).max() <= XY_ATOL       # xy within 1e-4 px
         assert np.array_equal(kp, fx["final_rn"])                               # in fact identical
-        kp2, _ = fn(golden.bgr, golden.n_ids, dc, None, draw_pred=False, device="cuda")
+        kp2, _ = fn(bgr, golden.n_ids, dc, None, draw_pred=False, device="cuda")
         assert kp2.dtype == np.int64 and np.array_equal(kp2, fx["final_norn"])
 
 
