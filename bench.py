@@ -36,36 +36,45 @@ REFERENCE_README_FPS = 200.0      # "> 200 fps" GTX1080Ti, bs=1 (RE
 
 
 def calibrate_dustbin(sd_dc, frames_dev, dev, n_ids=16, per_frame=16):
-    """Set convDb.bias[n_ids] so that ~per_frame cells fire per frame.  Uses the HIP
-    detector's own logits (setup only, outside every timed region)."""
+    """Set convDb.bias[n_ids] so that on average per_frame cells fire per frame.
+    Setup only (outside every timed region): HIP detector logits -> host numpy."""
     det = dcModel(n_ids, sd_dc, dev)
     out = det.forward_u8(frames_dev)
-    loc, ids = out["loc"], out["ids"]
+    loc, ids = out["loc"].cpu().numpy(), out["ids"].cpu().numpy()
     la = loc.argmax(1)
-    m = ids[:, :n_ids].max(1).values - ids[:, n_ids]
-    m = torch.where(la == 64, torch.full_like(m, -1e30), m).flatten().sort(descending=True).values
+    m = ids[:, :n_ids].max(1) - ids[:, n_ids]
+    m = np.sort(np.where(la == 64, -1e30, m).ravel())[::-1]
     k = per_frame * frames_dev.shape[0]
-    delta = float((m[k - 1] + m[k]) / 2)
+    delta = np.float32((m[k - 1] + m[k]) / 2)
     sd = {k_: v.copy() for k_, v in sd_dc.items()}
-    sd["convDb.bias"][n_ids] = np.float32(sd["convDb.bias"][n_ids] + np.float32(delta))
+    sd["convDb.bias"][n_ids] = np.float32(sd["convDb.bias"][n_ids] + delta)
+    del det
     return sd
 
 
-def cpu_baseline(sd_dc, sd_rn, frames_u8, budget_s=12.0, max_frames=48):
+def cpu_baseline(sd_dc, sd_rn, frames_u8, budget_s=18.0):
     """The oracle (CPU restatement of the reference, verified identical to it) timed on this host's
-    cores with the reference's own protocol (src/benchmark.py:37-53: bs=1 loop after warm-up)."""
+    cores with the reference's own protocol (src/benchmark.py:37-53: bs=1 loop after warm-up).
+    oneDNN at bs=1 does not scale to every core of a big host, so a few thread counts are tried
+    within the time budget and the fastest is reported together with the threads it used."""
     from oracle import deepcharuco_oracle as O
     t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
-    O.infer_image(None, 16, t_dc, t_rn, gray=frames_u8[0])   # warm-up
-    n = 0
-    t0 = time.time()
-    while n < max_frames and (time.time() - t0) < budget_s:
-        O.infer_image(None, 16, t_dc, t_rn, gray=frames_u8[n % len(frames_u8)])
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{n} frames 320x240 bs=1 through oracle.infer_image (torch-CPU fp32 restatement, "
-                      f"{dt:.1f}s, same weights/frames as the GPU run)"}
+    ncpu = os.cpu_count() or 1
+    tried = {}
+    cands = sorted({min(ncpu, c) for c in (8, 16, 32, ncpu)})
+    for c in cands:
+        torch.set_num_threads(c)
+        O.infer_image(None, 16, t_dc, t_rn, gray=frames_u8[0])   # warm-up
+        n, t0 = 0, time.time()
+        while (time.time() - t0) < budget_s / len(cands) and n < 64:
+            O.infer_image(None, 16, t_dc, t_rn, gray=frames_u8[n % len(frames_u8)])
+            n += 1
+        tried[c] = (n / (time.time() - t0), n)
+    best = max(tried, key=lambda c: tried[c][0])
+    return {"value": round(tried[best][0], 3), "unit": "frames/s", "cores": int(best), "kind": "port",
+            "sample": f"{tried[best][1]} frames 320x240, bs=1 loop through oracle.infer_image (torch-CPU fp32 restatement "
+                      f"of the reference, same weights/frames as the GPU run); threads tried "
+                      + ", ".join(f"{c}: {v[0]:.2f} fps" for c, v in tried.items()) + f"; host has {ncpu} logical CPUs"}
 
 
 def main():
@@ -76,7 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--width", type=int, default=320)
-    ap.add_argument("--kmax", type=int, default=32, help="corner capacity per frame")
+    ap.add_argument("--kmax", type=int, default=64, help="corner capacity per frame")
     ap.add_argument("--frames", default="board", choices=["board", "noise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -99,7 +108,7 @@ def main():
     B, H, Wd, kmax = args.batch, args.height, args.width, args.kmax
     frames = W.synthetic_frames(args.frames, 1000 + rank * B, B, H, Wd)
     d_frames = torch.from_numpy(frames).to(dev)
-    sd_dc = calibrate_dustbin(W.synthetic_state_dict("detector", 1234), d_frames[:8], dev)
+    sd_dc = calibrate_dustbin(W.synthetic_state_dict("detector", 1234), d_frames, dev)
     sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
 
