@@ -18,13 +18,13 @@
 //   float4 feeds MFMA j, so one ds_read_b128 + one global_load_dwordx4 per tile feed 4 MFMAs
 //   (256 cycles).  The resulting summation order is specified (and restated bit-exactly by
 //   oracle/conv_exact.c):
-//     acc = 0;  for chunk c (32 cin) / tap (dy-major) / s in 0..3 / j in 0..3:
+//     acc = 0;  for chunk c (16 cin) / tap (dy-major) / s in 0..1 / j in 0..3:
 //                  acc = fmaf(w[8s+j],   x[8s+j],   acc);     (k = 0 half)
 //                  acc = fmaf(w[8s+4+j], x[8s+4+j], acc);     (k = 1 half)
 //   i.e. an exact sequential fp32 fmaf chain (MFMA f32 numerics, cdna_hip_programming.md section 3).
 //
 // Activations: the (TH+2)x(TW+2) input halo tile of a 32-channel chunk is staged in LDS as
-//   sB[cq][halo_pixel] float4 -- consecutive lanes read consecutive 16-B slots (conflict-free
+//   sB[buf][cq][halo_pixel] float4 (double buffered, 16-channel chunks) -- consecutive lanes read consecutive 16-B slots (conflict-free
 //   ds_read_b128 without padding or swizzle).  Zero padding, the valid-conv offset and the nearest
 //   x2 up-sampling of RefineNet are all resolved while staging, so the MFMA loop is identical for
 //   every layer.  Weights ([tap][cin/4][cout][4], <= 1.2 MB, L2 resident) are streamed straight
@@ -33,8 +33,9 @@
 #include "dcx_common.h"
 
 typedef float dcx_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int dcx_u32x4 __attribute__((ext_vector_type(4)));
 
-#define DCX_CCH 32  // input channels staged per LDS chunk
+#define DCX_CCH 16  // input channels per LDS chunk ("unit" of the software pipeline)
 
 template <int WM_, int WN_, int MT_, int NT_, int TH_, int TW_, int KS_, bool POOL_, int EPI_>
 struct DcxConvCfg {
@@ -47,23 +48,66 @@ struct DcxConvCfg {
     static constexpr int TILE_PIX = TH * TW;
     static constexpr int HH = TH + KS - 1, HW = TW + KS - 1;
     static constexpr int HALO = HH * HW;
-    static constexpr int CQC = DCX_CCH / 4;
-    static constexpr int LDS_FLOAT4 = CQC * HALO;
-    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOAT4 * 16;
+    static constexpr int CQC = DCX_CCH / 4;           // channel quads per chunk
+    static constexpr int LDS_FLOAT4 = CQC * HALO;     // one staging buffer
+    static constexpr size_t LDS_BYTES = (size_t)2 * LDS_FLOAT4 * 16;   // double buffered
+    static constexpr int STEPS = KS * KS * (DCX_CCH / 8);              // MFMA k-steps (8 channels of one tap) per unit
+    static constexpr int ITER = (LDS_FLOAT4 + NTHREADS - 1) / NTHREADS;  // float4 pieces per thread per unit
+    static constexpr int DA = 2;                                          // weights are fetched DA k-steps ahead
+    static constexpr int DP = (STEPS - 1) < 3 ? (STEPS - 1) : 3;           // a staging piece is written DP steps after its load
+    static constexpr int LOAD_STEPS = STEPS - DP;                          // steps that issue staging loads
+    static constexpr int PPS = (ITER + LOAD_STEPS - 1) / LOAD_STEPS;       // pieces fetched per k-step
+    static constexpr int NPAIR = 2 * MT * NT;                              // MFMA pairs per k-step
+    // workgroups per CU the launch is sized for (registers: <= 168 VGPR+AGPR for 3 waves/SIMD)
+    static constexpr int OCC_LDS = (LDS_BYTES * 3 <= 160 * 1024) ? 3 : ((LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1);
+    static constexpr int OCC = OCC_LDS > 2 ? 2 : OCC_LDS;   // 2 workgroups/CU measured best; leaves 256 registers per lane
     static_assert(TILE_PIX <= CAP, "tile does not fit the wave layout");
     static_assert(!POOL || (TH % 2 == 0 && TW % 2 == 0), "pooled tiles must be even");
     static_assert(EPI != DCX_EPI_HEAT || (WM == 1 && !POOL), "heat epilogue needs all couts in one wave row");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
+    static_assert(STEPS >= 2, "pipeline needs two k-steps per unit");
 };
 
 __device__ __forceinline__ float4 dcx_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// lane exchange inside a quad of lanes (DPP quad_perm): 0xB1 = [1,0,3,2] (xor 1), 0x4E = [2,3,0,1] (xor 2)
+template <int CTRL>
+__device__ __forceinline__ float dcx_quad_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// One v_max_f32.  fmaxf() makes hipcc emit an extra canonicalising v_max per operand (sNaN quieting);
+// activations here are finite, and the epilogue runs with the matrix pipe idle, so every VALU counts.
+__device__ __forceinline__ float dcx_vmax(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ float4 dcx_quad_max(float4 v) {   // max over the 4 lanes of a quad (2x2 pooling window)
+    v.x = dcx_vmax(v.x, dcx_quad_perm<0xB1>(v.x)); v.y = dcx_vmax(v.y, dcx_quad_perm<0xB1>(v.y));
+    v.z = dcx_vmax(v.z, dcx_quad_perm<0xB1>(v.z)); v.w = dcx_vmax(v.w, dcx_quad_perm<0xB1>(v.w));
+    v.x = dcx_vmax(v.x, dcx_quad_perm<0x4E>(v.x)); v.y = dcx_vmax(v.y, dcx_quad_perm<0x4E>(v.y));
+    v.z = dcx_vmax(v.z, dcx_quad_perm<0x4E>(v.z)); v.w = dcx_vmax(v.w, dcx_quad_perm<0x4E>(v.w));
+    return v;
+}
+
+struct DcxItem {   // one work item = (image, cout tile, spatial tile); all fields wave-uniform
+    int n, ct, ty, tx;
+};
+
+// Persistent, software-pipelined kernel.
+//   work item  = (image n, cout tile, spatial tile);   unit = (work item, 16-channel chunk)
+//   Each workgroup walks its items (blockIdx.x, +gridDim.x, ...) unit by unit.  While the MFMAs of
+//   unit u run out of LDS buffer u&1, the halo tile of unit u+1 -- possibly the first chunk of the
+//   NEXT work item -- is fetched one float4 "piece" per k-step into registers and written to buffer
+//   (u+1)&1 one step later, so global-memory latency and the staging index math hide behind
+//   16 MFMAs (1024 cycles) per step.  Only the first unit of a workgroup is staged synchronously.
+//   One barrier per unit.  Weights (A) and LDS reads (B) are fetched one k-step ahead.
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS, 2) void dcx_conv_mfma_kernel(const DcxConvArgs a) {
+__global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(const DcxConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sB[];
     constexpr int WN = C::WN, MT = C::MT, NT = C::NT, TW = C::TW, KS = C::KS;
-    constexpr int HW = C::HW, HALO = C::HALO;
-    constexpr int STEPS = KS * KS * (DCX_CCH / 8);  // MFMA k-steps of 8 channels per chunk
+    constexpr int HW = C::HW, HALO = C::HALO, STEPS = C::STEPS, ITER = C::ITER, PPS = C::PPS;
+    constexpr int LDSF = C::LDS_FLOAT4, CQC = C::CQC;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -71,19 +115,29 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void dcx_conv_mfma_kernel(const Dcx
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
 
-    int bid = blockIdx.x;
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    // ---- work list --------------------------------------------------------------------------
+    const int tiles = a.tiles_x * a.tiles_y;
     const int n_ct = a.cout_pad / C::COUT_TILE;
-    const int ct = bid % n_ct;
-    const int n = bid / n_ct;
-    if (a.n_limit != nullptr && n >= *a.n_limit) return;
+    int n_eff = a.n;
+    if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
+    const int total = n_eff * n_ct * tiles;     // images are the slowest index: skipped ones are at the end
+    int w = blockIdx.x;
+    if (w >= total) return;
+    const int gstride = gridDim.x;
+    const int nch = a.cin / DCX_CCH;
+    auto decode = [&](int wi) {
+        DcxItem it;
+        it.tx = wi % a.tiles_x; wi /= a.tiles_x;
+        it.ty = wi % a.tiles_y; wi /= a.tiles_y;
+        it.ct = wi % n_ct;
+        it.n = wi / n_ct;
+        return it;
+    };
 
-    const int oy0 = ty * C::TH, ox0 = tx * C::TW;   // tile origin in conv-output coordinates
     const int hl = a.hin << a.ups, wl = a.win << a.ups;  // logical (up-sampled) input size
 
-    // ---- per-lane pixel of every n-tile -------------------------------------------------
-    int pixb[NT];      // halo-tile pixel index of the lane's output pixel (tap 0,0)
+    // ---- per-lane pixel of every n-tile (tile-relative, identical for every work item) ---------
+    int pixb[NT];      // halo-tile pixel index of the lane's output pixel (tap 0,0) + half*HALO
     int qys[NT], qxs[NT];
     bool qok[NT];
 #pragma unroll
@@ -106,17 +160,77 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void dcx_conv_mfma_kernel(const Dcx
         pixb[nt] = half * HALO + (ok ? qy * HW + qx : 0);
     }
 
-    // ---- weights: lane reads float4 #(cq * cout_pad + cout) --------------------------------
-    const int cq_total_in = a.cin >> 2;
-    const float4* wlane = reinterpret_cast<const float4*>(a.w)
-                        + (size_t)half * a.cout_pad + ct * C::COUT_TILE + wm * (MT * 32) + l31;
-    auto load_a = [&](int c0, int step, float4 (&dst)[MT]) {
+    // ---- operand fetch helpers -------------------------------------------------------------------
+    // A (weights): address = uniform unit base + 32-bit (lane offset + step offset); lane reads float4
+    // #(cq * cout_pad + cout) of tap `tap`, cq = chunk quad 2s + half.
+    const unsigned w_lane_off = (unsigned)((half * a.cout_pad) + wm * (MT * 32) + l31) * 16u;
+    const unsigned w_tap_stride = (unsigned)((a.cin >> 2) * a.cout_pad) * 16u;   // bytes between taps
+    const unsigned w_s_stride = (unsigned)(2 * a.cout_pad) * 16u;                 // bytes between 8-channel groups
+    auto unit_wbase = [&](const DcxItem& it, int c) {
+        return reinterpret_cast<const char*>(a.w) + ((size_t)(c * CQC) * a.cout_pad + (size_t)it.ct * C::COUT_TILE) * 16;
+    };
+    auto load_a = [&](const char* wbase, int step, float4 (&dst)[MT]) {
         const int tap = step / (DCX_CCH / 8);
         const int s = step - tap * (DCX_CCH / 8);
-        const size_t off = ((size_t)tap * cq_total_in + (c0 >> 2) + 2 * s) * (size_t)a.cout_pad;
+        const unsigned off = w_lane_off + (unsigned)tap * w_tap_stride + (unsigned)s * w_s_stride;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dst[mt] = wlane[off + mt * 32];
+        for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const float4*>(wbase + off + mt * 512);
     };
+    auto load_b = [&](int buf, int step, float4 (&dst)[NT]) {
+        const int tap = step / (DCX_CCH / 8);
+        const int s = step - tap * (DCX_CCH / 8);
+        const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dst[nt] = sB[buf * LDSF + pixb[nt] + (2 * s) * HALO + dy * HW + dx];
+    };
+    // halo staging.  Piece `pi` of a unit = float4 #(tid + pi*NTHREADS) of the [cq][halo pixel] tile.  Its
+    // (cq, hy, hx) never change, so they are computed once; per unit only the tile origin moves.
+    // The load is a raw buffer load whose descriptor covers exactly this unit's 4 channel quads:
+    // out-of-image taps (zero padding) get an out-of-range offset and the hardware returns 0.0f --
+    // no branch, no select, so the whole unit body stays one basic block the scheduler can interleave.
+    int p_hy[ITER], p_hx[ITER], p_cq[ITER];
+#pragma unroll
+    for (int pi = 0; pi < ITER; ++pi) {
+        const int idx = tid + pi * C::NTHREADS;
+        const int cq = idx / HALO;
+        const int hp = idx - cq * HALO;
+        p_hy[pi] = hp / HW;
+        p_hx[pi] = hp - p_hy[pi] * HW;
+        p_cq[pi] = idx < LDSF ? cq * a.hin : -1;      // pre-multiplied row base; -1 marks lanes past the tile
+    }
+    const unsigned chunk_bytes = (unsigned)CQC * a.hin * a.win * 16u;
+    auto unit_rsrc = [&](const DcxItem& it, int c) {
+        const float* base = a.in + ((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)chunk_bytes, 0x00020000);
+    };
+    auto stage_off = [&](int sy0, int sx0, int pi) {
+        const int ly = sy0 + p_hy[pi], lx = sx0 + p_hx[pi];
+        const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl && p_cq[pi] >= 0;
+        const unsigned off = (unsigned)((p_cq[pi] + (ly >> a.ups)) * a.win + (lx >> a.ups)) * 16u;
+        return inb ? off : 0x80000000u;   // out of range -> the buffer load returns zeros
+    };
+    auto stage_fetch = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto stage_store = [&](int buf, int pi, const float4& v) {
+        const int idx = tid + pi * C::NTHREADS;
+        if (idx < LDSF) sB[buf * LDSF + idx] = v;
+    };
+
+    // ---- epilogue constants: per-channel (bias, alpha, beta[, head weight]) staged in LDS once ---------
+    // layout after the two halo buffers: sP[k][cout_pad/4] float4, k = 0 bias, 1 alpha, 2 beta, 3 head_w
+    float4* sP = sB + 2 * LDSF;
+    const int cq_pad = a.cout_pad >> 2;
+    for (int i = tid; i < cq_pad; i += C::NTHREADS) {
+        sP[i] = reinterpret_cast<const float4*>(a.bias)[i];
+        if (C::EPI != DCX_EPI_RAW) {
+            sP[cq_pad + i] = reinterpret_cast<const float4*>(a.alpha)[i];
+            sP[2 * cq_pad + i] = reinterpret_cast<const float4*>(a.beta)[i];
+        }
+        if (C::EPI == DCX_EPI_HEAT) sP[3 * cq_pad + i] = reinterpret_cast<const float4*>(a.head_w)[i];
+    }
+    const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
 
     dcx_f32x16 acc[MT][NT];
 #pragma unroll
@@ -126,186 +240,250 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void dcx_conv_mfma_kernel(const Dcx
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    float4 a_cur[MT], a_nxt[MT];
-    load_a(0, 0, a_cur);
-
-    const float4* in4 = reinterpret_cast<const float4*>(a.in);
-    const size_t in_img = ((size_t)n * a.in_cq_total + a.in_cq_off) * (size_t)a.hin * a.win;
-
-    for (int c0 = 0; c0 < a.cin; c0 += DCX_CCH) {
-        // ---- stage the halo tile of channels [c0, c0+32) ---------------------------------
-        __syncthreads();   // everyone finished reading the previous chunk
-        {
-            constexpr int TOTAL = C::LDS_FLOAT4;
-            constexpr int ITER = (TOTAL + C::NTHREADS - 1) / C::NTHREADS;
-            float4 v[ITER];
-            const size_t chunk_base = in_img + (size_t)(c0 >> 2) * a.hin * a.win;
+    // ---- prologue: first unit staged synchronously ---------------------------------------------
+    DcxItem cur = decode(w);
+    int c = 0;
+    float4 a_c0[MT], a_c1[MT];      // weights of k-steps 0 and 1 of the unit about to run (carried across units)
+    {
+        const char* wb = unit_wbase(cur, 0);
+        load_a(wb, 0, a_c0);
+        load_a(wb, 1, a_c1);
+        const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(cur, 0);
+        const int sy0 = cur.ty * C::TH - a.pad, sx0 = cur.tx * C::TW - a.pad;
+        float4 v[ITER];
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                // branch-free: always load from a clamped (valid) address, then select zero
-                const int idx = min(tid + it * C::NTHREADS, TOTAL - 1);
-                const int cq = idx / HALO;
-                const int hp = idx - cq * HALO;
-                const int hy = hp / HW;
-                const int hx = hp - hy * HW;
-                const int ly = oy0 - a.pad + hy, lx = ox0 - a.pad + hx;
-                const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
-                const int cy = min(max(ly, 0), hl - 1) >> a.ups;
-                const int cx = min(max(lx, 0), wl - 1) >> a.ups;
-                const float4 t = in4[chunk_base + ((size_t)cq * a.hin + cy) * a.win + cx];
-                v[it] = inb ? t : dcx_f4_zero();
-            }
+        for (int pi = 0; pi < ITER; ++pi) v[pi] = stage_fetch(r0, stage_off(sy0, sx0, pi));
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int idx = tid + it * C::NTHREADS;
-                if (idx < TOTAL) sB[idx] = v[it];
-            }
+        for (int pi = 0; pi < ITER; ++pi) stage_store(0, pi, v[pi]);
+    }
+
+    for (int u = 0;; ++u) {
+        // ---- what comes after this unit (wave-uniform) ----------------------------------------------
+        DcxItem nxt = cur;
+        int cn = c + 1;
+        bool has_next = true;
+        if (cn == nch) {
+            if (w + gstride < total) { nxt = decode(w + gstride); cn = 0; }
+            else { has_next = false; cn = c; }   // nothing follows: harmlessly re-stage the current chunk
         }
-        __syncthreads();
+        const int buf = u & 1;
+        __syncthreads();   // unit u's tile is complete in sB[buf]; everyone is done reading sB[buf ^ 1]
 
-        // ---- 9 taps x 4 channel-octets, 4*MT*NT MFMAs each ----------------------------------
+        const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
+        const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
+        const char* wb_cur = unit_wbase(cur, c);
+        const char* wb_nxt = unit_wbase(nxt, cn);
+        // Software pipeline of one unit (everything below is ONE basic block, fully unrolled):
+        //   weights  A(t+DA)  are requested DA = 2 k-steps ahead (loads return in order, so the weight
+        //            loads queue behind the HBM-latency staging loads and need the extra distance),
+        //   LDS      B(t+1)   one step ahead,
+        //   staging  piece(t) of the NEXT unit is requested at step t and written to the other LDS
+        //            buffer DP = 3 steps later.
+        // A wave cannot issue past an MFMA that is waiting for the matrix pipe, so the non-MFMA work is
+        // cut into short slots placed after every PAIR of MFMAs (each slot issues in the shadow of the
+        // MFMA before it); sched_barrier(0) pins that order.
+        float4 aq[STEPS + C::DA][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { aq[0][mt] = a_c0[mt]; aq[1][mt] = a_c1[mt]; }
+        float4 bq[STEPS + 1][NT];
+        load_b(buf, 0, bq[0]);
+        float4 pv[STEPS][PPS];
+        unsigned poff[PPS];
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
-            const int tap = step / (DCX_CCH / 8);
-            const int s = step - tap * (DCX_CCH / 8);
-            const int dy = tap / KS, dx = tap - dy * KS;
-            if (step + 1 < STEPS) {
-                load_a(c0, step + 1, a_nxt);
-            } else if (c0 + DCX_CCH < a.cin) {
-                load_a(c0 + DCX_CCH, 0, a_nxt);
-            } else {
+            int pair = 0;
+            auto mfma_pair = [&]() {      // MFMAs 2*pair, 2*pair+1 of the step in (j, mt, nt) order
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = a_cur[mt];
-            }
-            float4 b[NT];
+                for (int e = 0; e < 2; ++e) {
+                    const int f = 2 * pair + e;
+                    const int j = f / (MT * NT), mt = (f / NT) % MT, nt = f % NT;
+                    const float4 av4 = aq[step][mt], bv4 = bq[step][nt];
+                    const float av = j == 0 ? av4.x : j == 1 ? av4.y : j == 2 ? av4.z : av4.w;
+                    const float bv = j == 0 ? bv4.x : j == 1 ? bv4.y : j == 2 ? bv4.z : bv4.w;
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0);
+                }
+                ++pair;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            // slot A: LDS operand of step+1
+            if (step + 1 < STEPS) load_b(buf, step + 1, bq[step + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pair < C::NPAIR) mfma_pair();
+            // slot B: weights of step+DA (of the next unit near the end)
+            if (step + C::DA < STEPS) load_a(wb_cur, step + C::DA, aq[step + C::DA]);
+            else load_a(wb_nxt, step + C::DA - STEPS, aq[step + C::DA]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pair < C::NPAIR) mfma_pair();
+            // slot C: address of this step's staging piece(s) of the next unit
+            if (step < C::LOAD_STEPS) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = sB[pixb[nt] + (2 * s) * HALO + dy * HW + dx];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float av[4] = {a_cur[mt].x, a_cur[mt].y, a_cur[mt].z, a_cur[mt].w};
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float bv[4] = {b[nt].x, b[nt].y, b[nt].z, b[nt].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[mt][nt], 0, 0, 0);
+                for (int k = 0; k < PPS; ++k) {
+                    const int pi = step * PPS + k;
+                    if (pi < ITER) poff[k] = stage_off(nsy0, nsx0, pi);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pair < C::NPAIR) mfma_pair();
+            // slot D: request them
+            if (step < C::LOAD_STEPS) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+                for (int k = 0; k < PPS; ++k) {
+                    const int pi = step * PPS + k;
+                    if (pi < ITER) pv[step][k] = stage_fetch(rs_n, poff[k]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pair < C::NPAIR) mfma_pair();
+            // slot E: the piece(s) requested DP steps ago have landed: write them to the other LDS buffer
+            if (step >= C::DP) {
+#pragma unroll
+                for (int k = 0; k < PPS; ++k) {
+                    const int pi = (step - C::DP) * PPS + k;
+                    if (pi < ITER) stage_store(buf ^ 1, pi, pv[step - C::DP][k]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rest = 4; rest < C::NPAIR; ++rest) mfma_pair();
         }
-    }
-
-    // ---- epilogue ----------------------------------------------------------------------------
-    const float4* bias4 = reinterpret_cast<const float4*>(a.bias);
-    const float4* alpha4 = reinterpret_cast<const float4*>(a.alpha);
-    const float4* beta4 = reinterpret_cast<const float4*>(a.beta);
-    const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
-    float4* out4 = reinterpret_cast<float4*>(a.out);
-
-    float hsum[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) hsum[nt] = 0.f;
+        for (int mt = 0; mt < MT; ++mt) { a_c0[mt] = aq[STEPS][mt]; a_c1[mt] = aq[STEPS + 1][mt]; }
 
+        if (c == nch - 1) {
+            // ---- epilogue of work item `cur` ------------------------------------------------------
+            const int oy0 = cur.ty * C::TH, ox0 = cur.tx * C::TW;
+            const int n = cur.n;
+            float hsum[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cq = (ct * C::COUT_TILE >> 2) + (wm * MT + mt) * 8 + 2 * g + half;  // output channel quad
-            const float4 bi = bias4[cq];
-            float4 al = dcx_f4_zero(), be = dcx_f4_zero(), hw4 = dcx_f4_zero();
-            if (C::EPI != DCX_EPI_RAW) { al = alpha4[cq]; be = beta4[cq]; }
-            if (C::EPI == DCX_EPI_HEAT) hw4 = reinterpret_cast<const float4*>(a.head_w)[cq];
+            for (int nt = 0; nt < NT; ++nt) hsum[nt] = 0.f;
+            // output addressing: uniform 64-bit base of this wave's first channel quad + uniform plane
+            // offset per (mt, g) + one 32-bit per-lane offset per n-tile
+            const unsigned plane = (unsigned)(hs * ws);          // float4 per channel quad of one image
+            const int cq_w0 = (cur.ct * C::COUT_TILE >> 2) + wm * MT * 8;
+            char* obase = reinterpret_cast<char*>(a.out)
+                        + ((size_t)n * a.out_cq_total + a.out_cq_off + cq_w0) * (size_t)plane * 16;
+            unsigned lane_off[NT];
+            bool pix_ok[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1],
-                                       acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
-                v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
-                if (C::EPI != DCX_EPI_RAW) {
-                    v.x = fmaxf(fmaf(v.x, al.x, be.x), 0.f);
-                    v.y = fmaxf(fmaf(v.y, al.y, be.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, al.z, be.z), 0.f);
-                    v.w = fmaxf(fmaf(v.w, al.w, be.w), 0.f);
-                }
-                if (C::EPI == DCX_EPI_HEAT) {
-                    float h = hsum[nt];
-                    h = fmaf(v.x, hw4.x, h); h = fmaf(v.y, hw4.y, h);
-                    h = fmaf(v.z, hw4.z, h); h = fmaf(v.w, hw4.w, h);
-                    hsum[nt] = h;
-                    continue;
-                }
                 int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
-                bool ok = qok[nt] && sy < a.ho && sx < a.wo && cq < a.cout_quads;
-                if (C::POOL) {
-                    float4 o;
-                    o.x = __shfl_xor(v.x, 1); o.y = __shfl_xor(v.y, 1); o.z = __shfl_xor(v.z, 1); o.w = __shfl_xor(v.w, 1);
-                    v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
-                    o.x = __shfl_xor(v.x, 2); o.y = __shfl_xor(v.y, 2); o.z = __shfl_xor(v.z, 2); o.w = __shfl_xor(v.w, 2);
-                    v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
-                    ok = ok && (l31 & 3) == 0;
-                    sy >>= 1; sx >>= 1;
+                bool ok = qok[nt] && sy < a.ho && sx < a.wo;
+                if (C::POOL) { ok = ok && (l31 & 3) == 0; sy >>= 1; sx >>= 1; }
+                pix_ok[nt] = ok;
+                lane_off[nt] = ((unsigned)half * plane + (unsigned)(sy * ws + sx)) * 16u;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 bi[4], al[4], be[4], hw4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {   // batch the LDS reads of this m-tile's 4 channel quads
+                    const int cq = (cur.ct * C::COUT_TILE >> 2) + (wm * MT + mt) * 8 + 2 * g + half;
+                    bi[g] = sP[cq];
+                    if (C::EPI != DCX_EPI_RAW) { al[g] = sP[cq_pad + cq]; be[g] = sP[2 * cq_pad + cq]; }
+                    if (C::EPI == DCX_EPI_HEAT) hw4[g] = sP[3 * cq_pad + cq];
                 }
-                if (ok) {
-                    const size_t o = (((size_t)n * a.out_cq_total + a.out_cq_off + cq) * hs + sy) * (size_t)ws + sx;
-                    out4[o] = v;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cq = (cur.ct * C::COUT_TILE >> 2) + (wm * MT + mt) * 8 + 2 * g + half;  // output channel quad
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1],
+                                               acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+                        v.x += bi[g].x; v.y += bi[g].y; v.z += bi[g].z; v.w += bi[g].w;
+                        if (C::EPI != DCX_EPI_RAW) {
+                            v.x = dcx_vmax(fmaf(v.x, al[g].x, be[g].x), 0.f);
+                            v.y = dcx_vmax(fmaf(v.y, al[g].y, be[g].y), 0.f);
+                            v.z = dcx_vmax(fmaf(v.z, al[g].z, be[g].z), 0.f);
+                            v.w = dcx_vmax(fmaf(v.w, al[g].w, be[g].w), 0.f);
+                        }
+                        if (C::EPI == DCX_EPI_HEAT) {
+                            float h = hsum[nt];
+                            h = fmaf(v.x, hw4[g].x, h); h = fmaf(v.y, hw4[g].y, h);
+                            h = fmaf(v.z, hw4[g].z, h); h = fmaf(v.w, hw4[g].w, h);
+                            hsum[nt] = h;
+                            continue;
+                        }
+                        if (C::POOL) v = dcx_quad_max(v);
+                        if (pix_ok[nt] && cq < a.cout_quads)
+                            *reinterpret_cast<float4*>(obase + (size_t)((unsigned)(mt * 8 + 2 * g) * plane * 16u) + lane_off[nt]) = v;
+                    }
                 }
             }
-        }
-    }
 
-    if (C::EPI == DCX_EPI_HEAT) {
-        // 1x1 conv to one channel (refinenet.py:81 convPb) + arg-max of this tile (model_utils.py:39-43)
-        float best = -INFINITY;
-        int besti = 0x7fffffff;
+            if (C::EPI == DCX_EPI_HEAT) {
+                // 1x1 conv to one channel (refinenet.py:81 convPb) + arg-max of this tile (model_utils.py:39-43)
+                float best = -INFINITY;
+                int besti = 0x7fffffff;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float tot = hsum[nt] + __shfl_xor(hsum[nt], 32);   // both halves: couts 4*half+{0..3} interleaved
-            const float logit = tot + a.head_b;
-            const int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
-            const bool ok = qok[nt] && sy < a.ho && sx < a.wo;
-            if (ok) {
-                const int idx = sy * a.wo + sx;
-                if (a.heat != nullptr && half == 0) a.heat[((size_t)n * a.ho + sy) * a.wo + sx] = logit;
-                if (logit > best || (logit == best && idx < besti)) { best = logit; besti = idx; }
-            }
-        }
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float tot = hsum[nt] + __shfl_xor(hsum[nt], 32);   // the two half-waves hold disjoint couts
+                    const float logit = tot + a.head_b;
+                    const int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
+                    const bool ok = qok[nt] && sy < a.ho && sx < a.wo;
+                    if (ok) {
+                        const int idx = sy * a.wo + sx;
+                        if (a.heat != nullptr && half == 0) a.heat[((size_t)n * a.ho + sy) * a.wo + sx] = logit;
+                        if (logit > best || (logit == best && idx < besti)) { best = logit; besti = idx; }
+                    }
+                }
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(best, off);
-            const int oi = __shfl_xor(besti, off);
-            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-        }
-        __syncthreads();   // all waves are done with sB
-        float* red_v = reinterpret_cast<float*>(sB);
-        int* red_i = reinterpret_cast<int*>(sB) + 16;
-        if (lane == 0) { red_v[wave] = best; red_i[wave] = besti; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < C::WM * C::WN; ++w) {
-                const float ov = red_v[w];
-                const int oi = red_i[w];
-                if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                for (int off = 16; off >= 1; off >>= 1) {
+                    const float ov = __shfl_xor(best, off);
+                    const int oi = __shfl_xor(besti, off);
+                    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                }
+                __syncthreads();   // all waves are done reading sB[buf]: reuse its head as reduction scratch
+                float* red_v = reinterpret_cast<float*>(sB + buf * LDSF);
+                int* red_i = reinterpret_cast<int*>(sB + buf * LDSF) + 16;
+                if (lane == 0) { red_v[wave] = best; red_i[wave] = besti; }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int wv = 1; wv < C::WM * C::WN; ++wv) {
+                        const float ov = red_v[wv];
+                        const int oi = red_i[wv];
+                        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                    }
+                    a.part_val[(size_t)n * tiles + cur.ty * a.tiles_x + cur.tx] = best;
+                    a.part_idx[(size_t)n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
+                }
             }
-            const int tiles = a.tiles_x * a.tiles_y;
-            a.part_val[(size_t)n * tiles + ty * a.tiles_x + tx] = best;
-            a.part_idx[(size_t)n * tiles + ty * a.tiles_x + tx] = besti;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
+
+        if (!has_next) break;
+        if (cn == 0) w += gstride;
+        cur = nxt;
+        c = cn;
     }
 }
+
+int dcx_device_cu_count();   // dcx_conv_mfma.hip
+int dcx_occupancy_override();
 
 template <class C>
 static int dcx_conv_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     a.tiles_x = (a.wo + C::TW - 1) / C::TW;
     a.tiles_y = (a.ho + C::TH - 1) / C::TH;
     if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0) return DCX_E_SHAPE;
-    const long blocks = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
-    if (blocks <= 0 || blocks > 0x7fffffffL) return DCX_E_SHAPE;
+    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
+    if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
+    const int occ_env = dcx_occupancy_override();                      // tuning knob (DCX_OCC), 0 = default
+    const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);   // persistent workgroups
+    const long blocks = items < resident ? items : resident;
     static bool attr_set = false;
     if (!attr_set) {
         DCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcx_conv_mfma_kernel<C>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES + 8192)));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dcx_conv_mfma_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
+    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 16;   // halo double buffer + 4 per-channel parameter arrays
+    if (lds > 160 * 1024) return DCX_E_SHAPE;
+    hipLaunchKernelGGL((dcx_conv_mfma_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), lds, stream, a);
     return (int)hipGetLastError();
 }

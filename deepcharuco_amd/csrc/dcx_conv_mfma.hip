@@ -1,6 +1,7 @@
 // dcx_conv_mfma.hip -- instantiations and tile selection for the MFMA convolution kernel.
 #include "dcx_conv_mfma.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -100,6 +101,25 @@ extern "C" int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, d
 
 // cout <= 64 uses the 64-cout wave layout; anything larger is padded to the 128-cout layouts' multiple.
 int dcx_conv_cout_pad(int cout) { return cout <= 64 ? 64 : (cout + 127) / 128 * 128; }
+
+int dcx_device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;   // MI355X
+    }
+    return cus;
+}
+
+int dcx_occupancy_override() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_OCC"); v = e ? atoi(e) : 0; }
+    return v;
+}
 
 int dcx_conv_heat_tiles(int ho, int wo) { return ((ho + 7) / 8) * ((wo + 31) / 32); }
 

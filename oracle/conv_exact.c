@@ -7,7 +7,7 @@
  * (deepcharuco_amd/csrc/dcx_conv_mfma.h header, DESIGN.md "Numerics"), so that kernel outputs can
  * be compared bit for bit:
  *   acc = 0
- *   for each 32-channel chunk c0, each tap (dy-major), s = 0..3, j = 0..3:
+ *   for each 16-channel chunk c0, each tap (dy-major), s = 0..1, j = 0..3:
  *       acc = fmaf(w[c0+8s+j],   x[c0+8s+j],   acc)
  *       acc = fmaf(w[c0+8s+4+j], x[c0+8s+4+j], acc)
  *   y = acc + bias;  y = max(fmaf(y, alpha, beta), 0)   with alpha = gamma * (1/sqrt(var+eps)),
@@ -48,11 +48,11 @@ void dcx_oracle_conv_exact(const float* x, int n, int cin, int h, int w, const f
                             acc = fmaf(wt[(size_t)co * taps + t], xv, acc);
                         }
                     } else {
-                        for (int c0 = 0; c0 < cin; c0 += 32)
+                        for (int c0 = 0; c0 < cin; c0 += 16)
                             for (int t = 0; t < taps; ++t) {
                                 const int iy = oy - pad + t / ks, ix = ox - pad + t % ks;
                                 const int inb = iy >= 0 && iy < h && ix >= 0 && ix < w;
-                                for (int s = 0; s < 4; ++s)
+                                for (int s = 0; s < 2; ++s)
                                     for (int j = 0; j < 4; ++j)
                                         for (int k = 0; k < 2; ++k) {
                                             const int ci = c0 + 8 * s + 4 * k + j;

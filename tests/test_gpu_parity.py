@@ -164,7 +164,7 @@ def test_conv_layer_against_torch_fp32(dev, case):
     err = (got - ref).abs().max().item()
     _report(f"conv_layer/{name}", err)
     assert not torch.isnan(got).any(), "unwritten output elements"
-    assert err <= 2e-5, f"{name}: max abs err {err}"
+    assert err <= LOGIT_ATOL, f"{name}: max abs err {err}"
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
