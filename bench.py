@@ -165,32 +165,38 @@ def main():
         ids_ = (C.c_int * n)(); nimg = (C.c_int * n)(); lim = (C.c_int * n)()
         fl = (C.c_double * n)(); ms = (C.c_float * n)()
         n = L.dcx_profile_fetch(ids_, nimg, lim, fl, ms, n)
+        ghz = (C.c_float * max(n, 1))()
+        L.dcx_profile_clocks(ghz, n)
         L.dcx_profile_enable(0)
         total_patches = float(np.minimum(counts[:B], kmax).sum()) if len(counts) >= B else 0.0
         agg = {}
         for i in range(n):
             name = L.dcx_profile_kernel_name(ids_[i]).decode()
             imgs = total_patches if lim[i] else nimg[i]     # RefineNet launches cover only the live patches
-            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
             a[0] += fl[i] * imgs
             a[1] += ms[i]
             a[2] += 1
+            a[3] += ghz[i] * ms[i]
         conv_ms = sum(a[1] for a in agg.values())
         conv_flop = sum(a[0] for a in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][1])
-        name, (flop, msum, launches) = dom
+        name, (flop, msum, launches, clk) = dom
         achieved = flop / (msum * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": name, "launches": launches,
                     "avg_launch_ms": round(msum / launches, 4),
                     "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3),
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "shader_clock_ghz": round(clk / msum, 3),
+                    "frac_at_measured_clock": round(achieved / (PEAK_F32_MFMA_TFLOPS * (clk / msum) / 2.4), 4),
                     "all_conv_kernels": {"achieved": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(conv_ms / args.steps, 3),
                                          "frac": round(conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
                     "per_kernel": {k: {"ms_per_step": round(v[1] / args.steps, 4),
                                        "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
-                                       "launches_per_step": v[2] / args.steps} for k, v in agg.items()}}
+                                       "launches_per_step": v[2] / args.steps,
+                                       "clock_ghz": round(v[3] / v[1], 3) if v[1] > 0 else None} for k, v in agg.items()}}
 
     if rank != 0:
         if world > 1:

@@ -73,6 +73,8 @@ SIGNATURES = {
     "dcx_profile_count": (_i, []),
     "dcx_profile_fetch": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_float), _i]),
     "dcx_profile_kernel_name": (C.c_char_p, [_i]),
+    "dcx_profile_clocks": (_i, [C.POINTER(C.c_float), _i]),
+    "dcx_profile_probe_words": (_i, [_i, C.POINTER(C.c_ulonglong)]),
 }
 
 

@@ -83,6 +83,8 @@ int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out) {
     if (rc == 0 && h.g != nullptr) {
         std::vector<float> al, be;
         fold_bn(h.g, h.be, h.mu, h.var, cout, l.cout_pad, al, be);
+        // MFMA epilogue evaluates y = fma(acc, alpha, beta2) with the conv bias folded in: beta2 = fma(bias, alpha, beta)
+        for (int i = 0; i < cout; ++i) be[i] = fmaf(h.b[i], al[i], be[i]);
         rc = upload(al, &l.alpha);
         if (rc == 0) rc = upload(be, &l.beta);
     }
@@ -164,7 +166,7 @@ DetWs det_layout(int n_ids, int b, int h, int w) {
 struct RefWs {
     size_t buf0, buf1, pval, pidx, total;
 };
-constexpr int kRefTiles = 16;     // 64x64 heat-map in 8x32 tiles
+constexpr int kRefTiles = 16;     // capacity: 64x64 heat-map in 8x32 tiles (8 tiles of 16x32 when the big tile is used)
 RefWs ref_layout(int p) {
     RefWs L;
     size_t off = 0;
@@ -414,15 +416,17 @@ extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches
         if (rc) return rc;
         float* t = src; src = dst; dst = t;
     }
+    int heat_tiles = 0;
     {   // convPa on the up-sampled 64x64 + BN + ReLU + convPb 1x1 + per-tile arg-max (refinenet.py:80-81,108-111)
         DcxConvArgs a = conv_args(rf->head_a, src, p, 16, 0, 32, 32, 1, 1, nullptr, 16, lim);
         a.head_w = rf->head_w; a.head_b = rf->head_b; a.heat = d_heat;
         a.part_val = (float*)(ws + L.pval); a.part_idx = (int*)(ws + L.pidx);
-        if (dcx_conv_heat_tiles(a.ho, a.wo) != kRefTiles) return DCX_E_SHAPE;
+        heat_tiles = dcx_conv_heat_tiles(a.ho, a.wo);
+        if (heat_tiles <= 0 || heat_tiles > kRefTiles) return DCX_E_SHAPE;
         rc = dcx_launch_conv_mfma(a, 3, 0, DCX_EPI_HEAT, s);
         if (rc) return rc;
     }
-    return dcx_launch_refine_finalize((const float*)(ws + L.pval), (const int*)(ws + L.pidx), kRefTiles, 64, p, lim,
+    return dcx_launch_refine_finalize((const float*)(ws + L.pval), (const int*)(ws + L.pidx), heat_tiles, 64, p, lim,
                                       d_table, d_corners, d_xy, s);
 }
 

@@ -30,6 +30,7 @@ struct DcxConvArgs {
     const float* beta;     // [cout_pad]  bn_beta - mean * alpha
     float* out;            // C4 [N][out_cq_total][Hs][Ws][4]; Hs = Ho (or Ho/2 when pooled)
     const int* n_limit;    // optional device int: images n >= *n_limit are skipped
+    unsigned long long* clk_probe;  // optional [4]: workgroup 0 stores {s_memtime, s_memrealtime} at start and end
     // DCX_EPI_HEAT only
     const float* head_w;   // [cout_pad] weights of the 1x1 conv to one channel
     float head_b;

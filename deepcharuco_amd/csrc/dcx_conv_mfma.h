@@ -60,7 +60,9 @@ struct DcxConvCfg {
     static constexpr int NPAIR = 2 * MT * NT;                              // MFMA pairs per k-step
     // workgroups per CU the launch is sized for (registers: <= 168 VGPR+AGPR for 3 waves/SIMD)
     static constexpr int OCC_LDS = (LDS_BYTES * 3 <= 160 * 1024) ? 3 : ((LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1);
-    static constexpr int OCC = OCC_LDS > 2 ? 2 : OCC_LDS;   // 2 workgroups/CU measured best; leaves 256 registers per lane
+    // 2 workgroups/CU measured best for 64-register accumulators (256 registers per lane); the big wave tiles
+    // (128 accumulator registers) run one workgroup per CU with the whole 512-register file
+    static constexpr int OCC = (MT * NT * 16 > 64) ? 1 : (OCC_LDS > 2 ? 2 : OCC_LDS);
     static_assert(TILE_PIX <= CAP, "tile does not fit the wave layout");
     static_assert(!POOL || (TH % 2 == 0 && TW % 2 == 0), "pooled tiles must be even");
     static_assert(EPI != DCX_EPI_HEAT || (WM == 1 && !POOL), "heat epilogue needs all couts in one wave row");
@@ -81,6 +83,21 @@ __device__ __forceinline__ float dcx_vmax(float x, float y) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
+}
+typedef float dcx_f32x2 __attribute__((ext_vector_type(2)));
+// y = x * al + be on 4 channels as two v_pk_fma_f32 (packed fp32: 2 results per VALU instruction)
+__device__ __forceinline__ float4 dcx_fma4(float4 x, float4 al, float4 be) {
+    const dcx_f32x2 lo = __builtin_elementwise_fma(dcx_f32x2{x.x, x.y}, dcx_f32x2{al.x, al.y}, dcx_f32x2{be.x, be.y});
+    const dcx_f32x2 hi = __builtin_elementwise_fma(dcx_f32x2{x.z, x.w}, dcx_f32x2{al.z, al.w}, dcx_f32x2{be.z, be.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+// max(x, quad_perm(x)) in ONE VALU instruction (v_max_f32 with a DPP source).  The s_nop covers the
+// "VALU write -> DPP read" hazard, which hipcc does not pad inside an asm statement.
+#define DCX_MAX_DPP(x, PERM) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "+v"(x))
+__device__ __forceinline__ float4 dcx_quad_max_fused(float4 v) {   // max over the 4 lanes of a quad
+    DCX_MAX_DPP(v.x, "[1,0,3,2]"); DCX_MAX_DPP(v.y, "[1,0,3,2]"); DCX_MAX_DPP(v.z, "[1,0,3,2]"); DCX_MAX_DPP(v.w, "[1,0,3,2]");
+    DCX_MAX_DPP(v.x, "[2,3,0,1]"); DCX_MAX_DPP(v.y, "[2,3,0,1]"); DCX_MAX_DPP(v.z, "[2,3,0,1]"); DCX_MAX_DPP(v.w, "[2,3,0,1]");
+    return v;
 }
 __device__ __forceinline__ float4 dcx_quad_max(float4 v) {   // max over the 4 lanes of a quad (2x2 pooling window)
     v.x = dcx_vmax(v.x, dcx_quad_perm<0xB1>(v.x)); v.y = dcx_vmax(v.y, dcx_quad_perm<0xB1>(v.y));
@@ -123,6 +140,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     const int total = n_eff * n_ct * tiles;     // images are the slowest index: skipped ones are at the end
     int w = blockIdx.x;
     if (w >= total) return;
+    if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+        a.clk_probe[0] = __builtin_amdgcn_s_memtime();
+        a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
+    }
     const int gstride = gridDim.x;
     const int nch = a.cin / DCX_CCH;
     auto decode = [&](int wi) {
@@ -166,15 +187,22 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     const unsigned w_lane_off = (unsigned)((half * a.cout_pad) + wm * (MT * 32) + l31) * 16u;
     const unsigned w_tap_stride = (unsigned)((a.cin >> 2) * a.cout_pad) * 16u;   // bytes between taps
     const unsigned w_s_stride = (unsigned)(2 * a.cout_pad) * 16u;                 // bytes between 8-channel groups
+    // buffer addressing: voffset = per-lane constant, soffset = uniform (unit base + step offset) in an SGPR,
+    // the m-tile stride (512 B) goes into the instruction's immediate field -> no VALU per load
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), (short)0, (int)((unsigned)KS * KS * w_tap_stride), 0x00020000);
     auto unit_wbase = [&](const DcxItem& it, int c) {
-        return reinterpret_cast<const char*>(a.w) + ((size_t)(c * CQC) * a.cout_pad + (size_t)it.ct * C::COUT_TILE) * 16;
+        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u;
     };
-    auto load_a = [&](const char* wbase, int step, float4 (&dst)[MT]) {
+    auto load_a = [&](unsigned wbase, int step, float4 (&dst)[MT]) {
         const int tap = step / (DCX_CCH / 8);
         const int s = step - tap * (DCX_CCH / 8);
-        const unsigned off = w_lane_off + (unsigned)tap * w_tap_stride + (unsigned)s * w_s_stride;
+        const unsigned soff = wbase + (unsigned)tap * w_tap_stride + (unsigned)s * w_s_stride;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const float4*>(wbase + off + mt * 512);
+        for (int mt = 0; mt < MT; ++mt) {
+            const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane_off + mt * 512, soff, 0);
+            dst[mt] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
     };
     auto load_b = [&](int buf, int step, float4 (&dst)[NT]) {
         const int tap = step / (DCX_CCH / 8);
@@ -188,7 +216,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     // The load is a raw buffer load whose descriptor covers exactly this unit's 4 channel quads:
     // out-of-image taps (zero padding) get an out-of-range offset and the hardware returns 0.0f --
     // no branch, no select, so the whole unit body stays one basic block the scheduler can interleave.
-    int p_hy[ITER], p_hx[ITER], p_cq[ITER];
+    // Per piece (constant for the whole kernel): halo coordinates and the byte offset RELATIVE to the tile
+    // origin, p_rel = ((cq*hin + ((hy-pad)>>ups) + pad) * win + ((hx-pad)>>ups) + pad) * 16; lanes past the
+    // end of the tile get the out-of-range marker.  The uniform tile origin goes into the descriptor base.
+    int p_hy[ITER], p_hx[ITER];
+    unsigned p_rel[ITER];
 #pragma unroll
     for (int pi = 0; pi < ITER; ++pi) {
         const int idx = tid + pi * C::NTHREADS;
@@ -196,18 +228,26 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         const int hp = idx - cq * HALO;
         p_hy[pi] = hp / HW;
         p_hx[pi] = hp - p_hy[pi] * HW;
-        p_cq[pi] = idx < LDSF ? cq * a.hin : -1;      // pre-multiplied row base; -1 marks lanes past the tile
+        const int prow = ((p_hy[pi] - a.pad) >> a.ups) + a.pad, pcol = ((p_hx[pi] - a.pad) >> a.ups) + a.pad;
+        p_rel[pi] = idx < LDSF ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
     }
-    const unsigned chunk_bytes = (unsigned)CQC * a.hin * a.win * 16u;
     auto unit_rsrc = [&](const DcxItem& it, int c) {
-        const float* base = a.in + ((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win * 4;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)chunk_bytes, 0x00020000);
+        // element (row (ty*TH>>ups) - pad, col (tx*TW>>ups) - pad) of the unit's first channel quad; for tiles on the
+        // top/left border this points before the tensor, but those lanes are masked and never dereferenced
+        const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
+        const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
+                                    + tile_off) * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
     };
-    auto stage_off = [&](int sy0, int sx0, int pi) {
+    // a tile is "interior" when its whole halo lies inside the (logical) image: no predicate needed at all
+    auto tile_interior = [&](const DcxItem& it) {
+        const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
+        return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + C::HW <= wl;
+    };
+    auto stage_off = [&](int sy0, int sx0, int pi) {   // general (border / overhanging tile) form
         const int ly = sy0 + p_hy[pi], lx = sx0 + p_hx[pi];
-        const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl && p_cq[pi] >= 0;
-        const unsigned off = (unsigned)((p_cq[pi] + (ly >> a.ups)) * a.win + (lx >> a.ups)) * 16u;
-        return inb ? off : 0x80000000u;   // out of range -> the buffer load returns zeros
+        const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+        return inb ? p_rel[pi] : 0x80000000u;   // out of range -> the buffer load returns zeros
     };
     auto stage_fetch = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
         const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
@@ -216,6 +256,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     auto stage_store = [&](int buf, int pi, const float4& v) {
         const int idx = tid + pi * C::NTHREADS;
         if (idx < LDSF) sB[buf * LDSF + idx] = v;
+    };
+    // same with the buffer base folded into one per-unit VGPR so each store is base + immediate
+    auto stage_store_at = [&](float4* wbase_lds, int pi, const float4& v) {
+        if (tid + pi * C::NTHREADS < LDSF) wbase_lds[pi * C::NTHREADS] = v;
     };
 
     // ---- epilogue constants: per-channel (bias, alpha, beta[, head weight]) staged in LDS once ---------
@@ -245,7 +289,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     int c = 0;
     float4 a_c0[MT], a_c1[MT];      // weights of k-steps 0 and 1 of the unit about to run (carried across units)
     {
-        const char* wb = unit_wbase(cur, 0);
+        const unsigned wb = unit_wbase(cur, 0);
         load_a(wb, 0, a_c0);
         load_a(wb, 1, a_c1);
         const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(cur, 0);
@@ -267,12 +311,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
             else { has_next = false; cn = c; }   // nothing follows: harmlessly re-stage the current chunk
         }
         const int buf = u & 1;
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[4 + 3 * u] = __builtin_amdgcn_s_memtime();
         __syncthreads();   // unit u's tile is complete in sB[buf]; everyone is done reading sB[buf ^ 1]
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[5 + 3 * u] = __builtin_amdgcn_s_memtime();
 
         const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
         const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
-        const char* wb_cur = unit_wbase(cur, c);
-        const char* wb_nxt = unit_wbase(nxt, cn);
+        const unsigned wb_cur = unit_wbase(cur, c);
+        const unsigned wb_nxt = unit_wbase(nxt, cn);
         // Software pipeline of one unit (everything below is ONE basic block, fully unrolled):
         //   weights  A(t+DA)  are requested DA = 2 k-steps ahead (loads return in order, so the weight
         //            loads queue behind the HBM-latency staging loads and need the extra distance),
@@ -287,8 +333,29 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         for (int mt = 0; mt < MT; ++mt) { aq[0][mt] = a_c0[mt]; aq[1][mt] = a_c1[mt]; }
         float4 bq[STEPS + 1][NT];
         load_b(buf, 0, bq[0]);
+        float4* lds_w = sB + (buf ^ 1) * LDSF + tid;   // this thread's slot 0 in the buffer being filled
         float4 pv[STEPS][PPS];
+        // staging address of the piece(s) a step requests, computed in four mini-slots during the step before
+        const bool n_interior = tile_interior(nxt);
+        bool p_in[PPS];
         unsigned poff[PPS];
+        auto off_part = [&](int part, int for_step) {
+            if (for_step >= C::LOAD_STEPS) return;
+#pragma unroll
+            for (int k = 0; k < PPS; ++k) {
+                const int pi = for_step * PPS + k;
+                if (pi >= ITER) continue;
+                if (n_interior) {                     // uniform: no VALU at all
+                    if (part == 3) poff[k] = p_rel[pi];
+                } else if (part == 0) {
+                    const int ly = nsy0 + p_hy[pi], lx = nsx0 + p_hx[pi];
+                    p_in[k] = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+                } else if (part == 3) {
+                    poff[k] = p_in[k] ? p_rel[pi] : 0x80000000u;   // out of range -> the buffer load returns zeros
+                }
+            }
+        };
+        off_part(0, 0); off_part(1, 0); off_part(2, 0); off_part(3, 0);   // step 0's piece (exposed once per unit)
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             int pair = 0;
@@ -315,17 +382,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
             else load_a(wb_nxt, step + C::DA - STEPS, aq[step + C::DA]);
             __builtin_amdgcn_sched_barrier(0);
             if (pair < C::NPAIR) mfma_pair();
-            // slot C: address of this step's staging piece(s) of the next unit
-            if (step < C::LOAD_STEPS) {
-#pragma unroll
-                for (int k = 0; k < PPS; ++k) {
-                    const int pi = step * PPS + k;
-                    if (pi < ITER) poff[k] = stage_off(nsy0, nsx0, pi);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (pair < C::NPAIR) mfma_pair();
-            // slot D: request them
+            // slot C: request this step's staging piece(s) of the next unit (address computed last step)
             if (step < C::LOAD_STEPS) {
 #pragma unroll
                 for (int k = 0; k < PPS; ++k) {
@@ -335,21 +392,30 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
             if (pair < C::NPAIR) mfma_pair();
-            // slot E: the piece(s) requested DP steps ago have landed: write them to the other LDS buffer
+            // slot D: the piece(s) requested DP steps ago have landed: write them to the other LDS buffer
             if (step >= C::DP) {
 #pragma unroll
                 for (int k = 0; k < PPS; ++k) {
                     const int pi = (step - C::DP) * PPS + k;
-                    if (pi < ITER) stage_store(buf ^ 1, pi, pv[step - C::DP][k]);
+                    if (pi < ITER) stage_store_at(lds_w, pi, pv[step - C::DP][k]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (pair < C::NPAIR) mfma_pair();
+            // mini-slots E0..E3: 2-4 VALU each of the NEXT step's staging address, one per MFMA pair
 #pragma unroll
-            for (int rest = 4; rest < C::NPAIR; ++rest) mfma_pair();
+            for (int part = 0; part < 4; ++part) {
+                off_part(part, step + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pair < C::NPAIR) mfma_pair();
+            }
+#pragma unroll
+            for (int rest = 8; rest < C::NPAIR; ++rest) mfma_pair();
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { a_c0[mt] = aq[STEPS][mt]; a_c1[mt] = aq[STEPS + 1][mt]; }
 
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[6 + 3 * u] = __builtin_amdgcn_s_memtime();
         if (c == nch - 1) {
             // ---- epilogue of work item `cur` ------------------------------------------------------
             const int oy0 = cur.ty * C::TH, ox0 = cur.tx * C::TW;
@@ -379,7 +445,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {   // batch the LDS reads of this m-tile's 4 channel quads
                     const int cq = (cur.ct * C::COUT_TILE >> 2) + (wm * MT + mt) * 8 + 2 * g + half;
-                    bi[g] = sP[cq];
+                    if (C::EPI == DCX_EPI_RAW) bi[g] = sP[cq];
                     if (C::EPI != DCX_EPI_RAW) { al[g] = sP[cq_pad + cq]; be[g] = sP[2 * cq_pad + cq]; }
                     if (C::EPI == DCX_EPI_HEAT) hw4[g] = sP[3 * cq_pad + cq];
                 }
@@ -390,12 +456,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                     for (int nt = 0; nt < NT; ++nt) {
                         float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1],
                                                acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
-                        v.x += bi[g].x; v.y += bi[g].y; v.z += bi[g].z; v.w += bi[g].w;
-                        if (C::EPI != DCX_EPI_RAW) {
-                            v.x = dcx_vmax(fmaf(v.x, al[g].x, be[g].x), 0.f);
-                            v.y = dcx_vmax(fmaf(v.y, al[g].y, be[g].y), 0.f);
-                            v.z = dcx_vmax(fmaf(v.z, al[g].z, be[g].z), 0.f);
-                            v.w = dcx_vmax(fmaf(v.w, al[g].w, be[g].w), 0.f);
+                        if (C::EPI == DCX_EPI_RAW) {
+                            v.x += bi[g].x; v.y += bi[g].y; v.z += bi[g].z; v.w += bi[g].w;
+                        } else {   // conv bias is folded into the BN shift: be = fma(bias, alpha, bn_beta - mean*alpha)
+                            v = dcx_fma4(v, al[g], be[g]);
+                            v.x = dcx_vmax(v.x, 0.f); v.y = dcx_vmax(v.y, 0.f);
+                            v.z = dcx_vmax(v.z, 0.f); v.w = dcx_vmax(v.w, 0.f);
                         }
                         if (C::EPI == DCX_EPI_HEAT) {
                             float h = hsum[nt];
@@ -404,7 +470,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                             hsum[nt] = h;
                             continue;
                         }
-                        if (C::POOL) v = dcx_quad_max(v);
+                        if (C::POOL) v = dcx_quad_max_fused(v);
                         if (pix_ok[nt] && cq < a.cout_quads)
                             *reinterpret_cast<float4*>(obase + (size_t)((unsigned)(mt * 8 + 2 * g) * plane * 16u) + lane_off[nt]) = v;
                     }
@@ -456,7 +522,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
 
-        if (!has_next) break;
+        if (!has_next) {
+            if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+                a.clk_probe[2] = __builtin_amdgcn_s_memtime();
+                a.clk_probe[3] = __builtin_amdgcn_s_memrealtime();
+            }
+            break;
+        }
         if (cn == 0) w += gstride;
         cur = nxt;
         c = cn;

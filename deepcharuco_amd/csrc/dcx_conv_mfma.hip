@@ -21,6 +21,7 @@ struct CfgEntry {
 //                C = 4x1 waves, 128 couts x 64 px
 const CfgEntry kCfgs[] = {
     // 3x3 + BN + ReLU
+    DCX_CFG(1, 4, 2, 4, 16, 32, 3, 0, DCX_EPI_BNRELU),   // big wave tile: 64 cout x 512 px, 1 workgroup/CU
     DCX_CFG(1, 4, 2, 2, 8, 32, 3, 0, DCX_EPI_BNRELU),
     DCX_CFG(1, 4, 2, 2, 12, 20, 3, 0, DCX_EPI_BNRELU),
     DCX_CFG(1, 4, 2, 2, 6, 40, 3, 0, DCX_EPI_BNRELU),
@@ -30,6 +31,7 @@ const CfgEntry kCfgs[] = {
     DCX_CFG(2, 2, 2, 2, 8, 16, 3, 0, DCX_EPI_BNRELU),
     DCX_CFG(4, 1, 1, 2, 8, 8, 3, 0, DCX_EPI_BNRELU),
     // 3x3 + BN + ReLU + 2x2 max-pool
+    DCX_CFG(1, 4, 2, 4, 16, 32, 3, 1, DCX_EPI_BNRELU),
     DCX_CFG(1, 4, 2, 2, 8, 32, 3, 1, DCX_EPI_BNRELU),
     DCX_CFG(1, 4, 2, 2, 12, 20, 3, 1, DCX_EPI_BNRELU),
     DCX_CFG(1, 4, 2, 2, 6, 40, 3, 1, DCX_EPI_BNRELU),
@@ -38,8 +40,15 @@ const CfgEntry kCfgs[] = {
     // 1x1, raw (image flattened to 1 x P by the caller)
     DCX_CFG(1, 4, 2, 2, 1, 256, 1, 0, DCX_EPI_RAW),
     // RefineNet head: 3x3 + BN + ReLU + 1x1 -> 1 channel + tile arg-max
+    DCX_CFG(1, 4, 2, 4, 16, 32, 3, 0, DCX_EPI_HEAT),
     DCX_CFG(1, 4, 2, 2, 8, 32, 3, 0, DCX_EPI_HEAT),
 };
+
+int dcx_big_tiles_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_BIG_TILES"); v = (e && atoi(e)) ? 0 : 1; }   // opt-in: measured slower
+    return v;
+}
 
 const CfgEntry* pick(int ho, int wo, int cout_pad, int ks, int pool, int epi) {
     const CfgEntry* best = nullptr;
@@ -49,6 +58,7 @@ const CfgEntry* pick(int ho, int wo, int cout_pad, int ks, int pool, int epi) {
         if (cout_pad % c.cout_tile != 0) continue;
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
         double score = (double)ho * wo / ((double)tiles * c.cap);   // useful fraction of the MFMA work
+        if (c.cap > 256 && (dcx_big_tiles_disabled() || score < 0.999)) continue;   // big tiles only on an exact fit
         // mild preference for the 64-cout layout (smaller halo re-read per flop) on ties
         if (c.cout_tile == 64) score += 1e-6;
         if (score > best_score) { best_score = score; best = &c; }
@@ -57,7 +67,10 @@ const CfgEntry* pick(int ho, int wo, int cout_pad, int ks, int pool, int epi) {
 }
 
 // ---- per-launch profiling ---------------------------------------------------------------------
-struct ProfRec { int kernel_id, n, limited; double flops_per_image; hipEvent_t e0, e1; };
+struct ProfRec { int kernel_id, n, limited; double flops_per_image; hipEvent_t e0, e1; int slot; };
+unsigned long long* g_clk_dev = nullptr;   // [kClkSlots][4] shader-clock probes of workgroup 0
+constexpr int kClkSlots = 1024;
+constexpr int kClkWords = 64;   // per launch: 4 clock words + 3 timestamps per unit for the first 20 units
 bool g_prof = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -84,6 +97,28 @@ extern "C" const char* dcx_profile_kernel_name(int id) {
     const int n = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
     return id >= 0 && id < n ? kCfgs[id].name : "?";
 }
+// raw probe words of record i (debug aid for kernel tuning; layout documented in dcx_conv_mfma.h)
+extern "C" int dcx_profile_probe_words(int record, unsigned long long* out64) {
+    if (!out64 || record < 0 || record >= kClkSlots || g_clk_dev == nullptr) return DCX_E_ARG;
+    DCX_CHECK_HIP(hipMemcpy(out64, g_clk_dev + (size_t)kClkWords * record, kClkWords * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dcx_profile_clocks(float* ghz, int max_records) {
+    if (!ghz) return DCX_E_ARG;
+    const int n = (int)g_recs.size() < max_records ? (int)g_recs.size() : max_records;
+    std::vector<unsigned long long> h((size_t)kClkWords * kClkSlots, 0ull);
+    if (g_clk_dev != nullptr) DCX_CHECK_HIP(hipMemcpy(h.data(), g_clk_dev, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        ghz[i] = 0.f;
+        if (i < kClkSlots) {
+            const unsigned long long* p = &h[(size_t)kClkWords * i];
+            if (p[3] > p[1]) ghz[i] = (float)((double)(p[2] - p[0]) / (double)(p[3] - p[1]) * 0.1);   // realtime = 100 MHz
+        }
+    }
+    return n;
+}
+
 extern "C" int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, double* flops_per_image, float* ms,
                                  int max_records) {
     if (!kernel_ids || !n_images || !limited || !flops_per_image || !ms) return DCX_E_ARG;
@@ -121,7 +156,10 @@ int dcx_occupancy_override() {
     return v;
 }
 
-int dcx_conv_heat_tiles(int ho, int wo) { return ((ho + 7) / 8) * ((wo + 31) / 32); }
+int dcx_conv_heat_tiles(int ho, int wo) {
+    const CfgEntry* c = pick(ho, wo, 64, 3, 0, DCX_EPI_HEAT);
+    return c ? ((ho + c->th - 1) / c->th) * ((wo + c->tw - 1) / c->tw) : 0;
+}
 
 int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t stream) {
     if (a.in == nullptr || a.w == nullptr || a.bias == nullptr) return DCX_E_ARG;
@@ -139,6 +177,12 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
                       * (double)a.ho * a.wo;
     r.e0 = prof_event();
     r.e1 = prof_event();
+    r.slot = (int)g_recs.size();
+    if (g_clk_dev == nullptr) {
+        if (hipMalloc((void**)&g_clk_dev, sizeof(unsigned long long) * kClkWords * kClkSlots) != hipSuccess) g_clk_dev = nullptr;
+        else (void)hipMemset(g_clk_dev, 0, sizeof(unsigned long long) * kClkWords * kClkSlots);
+    }
+    if (g_clk_dev != nullptr && r.slot < kClkSlots) a.clk_probe = g_clk_dev + (size_t)kClkWords * r.slot;
     if (!r.e0 || !r.e1) return (int)hipErrorOutOfMemory;
     DCX_CHECK_HIP(hipEventRecord(r.e0, stream));
     const int rc = c->launch(a, stream);

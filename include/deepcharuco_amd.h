@@ -173,6 +173,12 @@ int dcx_profile_count(void);
 int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, double* flops_per_image, float* ms,
                       int max_records);
 const char* dcx_profile_kernel_name(int kernel_id);
+/* effective shader clock (GHz) seen by workgroup 0 of each recorded launch: s_memtime ticks per
+ * s_memrealtime (100 MHz) tick between its first and last instruction.  Same order as _fetch. */
+int dcx_profile_clocks(float* ghz, int max_records);
+/* raw 64 probe words of one recorded launch (kernel-tuning aid): [0..3] start/end {s_memtime, s_memrealtime},
+ * then for the first 20 units of workgroup 0: s_memtime before the unit barrier, after it, after the MFMA loop */
+int dcx_profile_probe_words(int record, unsigned long long* out64);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,9 @@
  *   for each 16-channel chunk c0, each tap (dy-major), s = 0..1, j = 0..3:
  *       acc = fmaf(w[c0+8s+j],   x[c0+8s+j],   acc)
  *       acc = fmaf(w[c0+8s+4+j], x[c0+8s+4+j], acc)
- *   y = acc + bias;  y = max(fmaf(y, alpha, beta), 0)   with alpha = gamma * (1/sqrt(var+eps)),
- *                                                        beta = bn_beta - mean*alpha  (fp32)
+ *   y = max(fmaf(acc, alpha, beta2), 0)   with alpha = gamma * (1/sqrt(var+eps)), beta = bn_beta - mean*alpha,
+ *                                          beta2 = fmaf(bias, alpha, beta)  (conv bias folded into the BN shift; fp32)
+ *   (raw 1x1 heads: y = acc + bias;  Cin = 1 first layers: y = max(fmaf(acc + bias, alpha, beta), 0))
  * For cin == 1 (first layers) the order is simply tap 0..8.
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC   (see oracle/Makefile)
  */
@@ -61,8 +62,10 @@ void dcx_oracle_conv_exact(const float* x, int n, int cin, int h, int w, const f
                                         }
                             }
                     }
-                    float v = acc + bias[co];
-                    if (alpha) v = fmaxf(fmaf(v, alpha[co], beta[co]), 0.0f);
+                    float v;
+                    if (alpha == NULL) v = acc + bias[co];                       /* raw 1x1 heads */
+                    else if (cin == 1) v = fmaxf(fmaf(acc + bias[co], alpha[co], beta[co]), 0.0f);   /* direct first layers */
+                    else v = fmaxf(fmaf(acc, alpha[co], fmaf(bias[co], alpha[co], beta[co])), 0.0f);   /* MFMA layers: bias folded */
                     y[(((size_t)b * cout + co) * ho + oy) * wo + ox] = v;
                 }
 }
