@@ -52,6 +52,17 @@ def calibrate_dustbin(sd_dc, frames_dev, dev, n_ids=16, per_frame=16):
     return sd
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE); None when no profile matches."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        return d.get(kernel_name)
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd_dc, sd_rn, frames_u8, budget_s=18.0):
     """The oracle (CPU restatement of the reference, verified identical to it) timed on this host's
     cores with the reference's own protocol (src/benchmark.py:37-53: bs=1 loop after warm-up).
@@ -133,10 +144,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import ctypes as C
+
+    def fetch_profile(total_patches):
+        """-> {kernel name: [flop, ms, launches, clock-weighted ms]} of the launches recorded since profile_enable(1)."""
+        n = L.dcx_profile_count()
+        ids_ = (C.c_int * max(n, 1))(); nimg = (C.c_int * max(n, 1))(); lim = (C.c_int * max(n, 1))()
+        fl = (C.c_double * max(n, 1))(); ms = (C.c_float * max(n, 1))(); ghz = (C.c_float * max(n, 1))()
+        n = L.dcx_profile_fetch(ids_, nimg, lim, fl, ms, n)
+        L.dcx_profile_clocks(ghz, n)
+        agg = {}
+        for i in range(n):
+            imgs = total_patches if lim[i] else nimg[i]     # RefineNet launches cover only the live patches
+            a = agg.setdefault(int(ids_[i]), [0.0, 0.0, 0, 0.0])
+            a[0] += fl[i] * imgs
+            a[1] += ms[i]
+            a[2] += 1
+            a[3] += ghz[i] * ms[i]
+        return agg
+
+    # warm-up (every conv launch hipEvent-bracketed: finds the dominant kernel for the timed region)
+    if not args.no_profile:
+        L.dcx_profile_filter(-1)
+        L.dcx_profile_enable(1)
     for _ in range(args.warmup):
         step()
     fence()
+    dom_id = -1
     if not args.no_profile:
+        warm = fetch_profile(16.0 * B)
+        L.dcx_profile_enable(0)
+        if warm:
+            dom_id = max(warm.items(), key=lambda kv: kv[1][1])[0]
+        L.dcx_profile_filter(dom_id)          # timed region: only the dominant kernel is bracketed (2 launches/step)
         L.dcx_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -156,47 +196,42 @@ def main():
         counts = unpack_results(host_local.numpy(), B, kmax, True)[1]
     mean_k = float(np.minimum(counts, kmax).mean())
     overflow = int((counts > kmax).sum())
+    total_patches = float(np.minimum(counts[:B], kmax).sum()) if len(counts) >= B else 0.0
 
-    # ---- roofline of the dominant kernel (hipEvent-bracketed launches inside the timed region)
+    # ---- roofline of the dominant kernel: its launches inside the timed region, hipEvent-bracketed on the
+    # stream they run on; the per-kernel table comes from 3 extra, fully bracketed steps after the timed region
     roofline = None
     if not args.no_profile:
-        n = L.dcx_profile_count()
-        import ctypes as C
-        ids_ = (C.c_int * n)(); nimg = (C.c_int * n)(); lim = (C.c_int * n)()
-        fl = (C.c_double * n)(); ms = (C.c_float * n)()
-        n = L.dcx_profile_fetch(ids_, nimg, lim, fl, ms, n)
-        ghz = (C.c_float * max(n, 1))()
-        L.dcx_profile_clocks(ghz, n)
+        timed = fetch_profile(total_patches)
         L.dcx_profile_enable(0)
-        total_patches = float(np.minimum(counts[:B], kmax).sum()) if len(counts) >= B else 0.0
-        agg = {}
-        for i in range(n):
-            name = L.dcx_profile_kernel_name(ids_[i]).decode()
-            imgs = total_patches if lim[i] else nimg[i]     # RefineNet launches cover only the live patches
-            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
-            a[0] += fl[i] * imgs
-            a[1] += ms[i]
-            a[2] += 1
-            a[3] += ghz[i] * ms[i]
-        conv_ms = sum(a[1] for a in agg.values())
-        conv_flop = sum(a[0] for a in agg.values())
-        dom = max(agg.items(), key=lambda kv: kv[1][1])
-        name, (flop, msum, launches, clk) = dom
+        L.dcx_profile_filter(-1)
+        L.dcx_profile_enable(1)
+        extra_steps = 3
+        for _ in range(extra_steps):
+            step()
+        fence()
+        full = fetch_profile(total_patches)
+        L.dcx_profile_enable(0)
+        kname = lambda k: L.dcx_profile_kernel_name(k).decode()
+        flop, msum, launches, clk = timed[dom_id]
         achieved = flop / (msum * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": name, "launches": launches,
+        conv_ms = sum(a[1] for a in full.values())
+        conv_flop = sum(a[0] for a in full.values())
+        roofline = {"bound": "mfma", "kernel": kname(dom_id), "launches": launches,
                     "avg_launch_ms": round(msum / launches, 4),
                     "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3),
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kname(dom_id)),
                     "shader_clock_ghz": round(clk / msum, 3),
-                    "frac_at_measured_clock": round(achieved / (PEAK_F32_MFMA_TFLOPS * (clk / msum) / 2.4), 4),
                     "all_conv_kernels": {"achieved": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2),
-                                         "ms_per_step": round(conv_ms / args.steps, 3),
-                                         "frac": round(conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-                    "per_kernel": {k: {"ms_per_step": round(v[1] / args.steps, 4),
-                                       "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
-                                       "launches_per_step": v[2] / args.steps,
-                                       "clock_ghz": round(v[3] / v[1], 3) if v[1] > 0 else None} for k, v in agg.items()}}
+                                         "ms_per_step": round(conv_ms / extra_steps, 3),
+                                         "frac": round(conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                         "source": f"{extra_steps} fully bracketed steps after the timed region"},
+                    "per_kernel": {kname(k): {"ms_per_step": round(v[1] / extra_steps, 4),
+                                              "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
+                                              "launches_per_step": v[2] / extra_steps,
+                                              "clock_ghz": round(v[3] / v[1], 3) if v[1] > 0 else None}
+                                   for k, v in full.items()}}
 
     if rank != 0:
         if world > 1:

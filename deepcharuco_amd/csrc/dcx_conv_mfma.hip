@@ -72,6 +72,7 @@ unsigned long long* g_clk_dev = nullptr;   // [kClkSlots][4] shader-clock probes
 constexpr int kClkSlots = 1024;
 constexpr int kClkWords = 64;   // per launch: 4 clock words + 3 timestamps per unit for the first 20 units
 bool g_prof = false;
+int g_prof_filter = -1;   // -1: record every launch; k: only launches of kernel id k
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_used = 0;
@@ -92,6 +93,7 @@ extern "C" int dcx_profile_enable(int enabled) {
     if (g_prof) { g_recs.clear(); g_pool_used = 0; }
     return 0;
 }
+extern "C" int dcx_profile_filter(int kernel_id) { g_prof_filter = kernel_id; return 0; }
 extern "C" int dcx_profile_count(void) { return (int)g_recs.size(); }
 extern "C" const char* dcx_profile_kernel_name(int id) {
     const int n = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
@@ -168,7 +170,7 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
     if (pool && ((a.ho | a.wo) & 1)) return DCX_E_SHAPE;
     const CfgEntry* c = pick(a.ho, a.wo, a.cout_pad, ks, pool, epi);
     if (c == nullptr) return DCX_E_SHAPE;
-    if (!g_prof) return c->launch(a, stream);
+    if (!g_prof || (g_prof_filter >= 0 && g_prof_filter != (int)(c - kCfgs))) return c->launch(a, stream);
     ProfRec r;
     r.kernel_id = (int)(c - kCfgs);
     r.n = a.n;

@@ -170,6 +170,8 @@ int dcx_last_timings(float* h_ms4);
  * of them), flops_per_image[i] = 2*cout*cin*ks*ks*Ho*Wo (algorithmic, un-padded), ms[i].      */
 int dcx_profile_enable(int enabled);
 int dcx_profile_count(void);
+/* restrict recording to one kernel id (-1 = all): keeps the event overhead out of a timed region */
+int dcx_profile_filter(int kernel_id);
 int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, double* flops_per_image, float* ms,
                       int max_records);
 const char* dcx_profile_kernel_name(int kernel_id);

@@ -403,3 +403,43 @@ def test_full_size_batch_properties(dev):
         tot += 0 if exp.ndim == 1 else exp.shape[0]
     _report("full_size/total_corners_32_frames", int(sum(0 if r.ndim == 1 else r.shape[0] for r in res)))
     assert tot > 0
+
+
+def test_config3_bs128_640x480(dev):
+    """BASELINE configs[2]: bs=128 at 640x480 on one GPU (4,800 cells/frame, 12.6 GB workspace): the batch
+    equals the oracle on sampled frames and is independent of batch position."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 500, 128, 480, 640)
+    sd_dc = _calibrated(77, frames[:2], target_per_frame=16)
+    sd_rn = W.synthetic_state_dict("refinenet", 78)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    res = infer_batch(frames, 16, dc, rn, kmax=64)
+    assert len(res) == 128
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    n_checked = 0
+    for b in (0, 1, 64, 127):
+        exp = O.infer_image(None, 16, t_dc, t_rn, gray=frames[b])
+        assert res[b].shape == exp.shape and np.array_equal(res[b], exp), f"frame {b}"
+        n_checked += 0 if exp.ndim == 1 else exp.shape[0]
+    alone = infer_batch(frames[64:65], 16, dc, rn, kmax=64)[0]
+    assert np.array_equal(alone, res[64])
+    _report("config3/corners_checked", n_checked)
+    assert n_checked > 0
+
+
+def test_config5_resolution_1280x960(dev):
+    """BASELINE configs[4] resolution (1280x960, 19,200 cells/frame), 2 frames: equals the oracle."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 900, 2, 960, 1280)
+    sd_dc = _calibrated(91, frames[:1], target_per_frame=16)
+    sd_rn = W.synthetic_state_dict("refinenet", 92)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    res = infer_batch(frames, 16, dc, rn, kmax=64)
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    for b in range(2):
+        exp = O.infer_image(None, 16, t_dc, t_rn, gray=frames[b])
+        assert res[b].shape == exp.shape and np.array_equal(res[b], exp), f"frame {b}"
