@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--frames", default="board", choices=["board", "noise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo only to smoke-test the multi-process flow "
+                         "with several ranks on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,34 +110,45 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but only {ndev} GPUs visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     L = _lib.lib()
 
     B, H, Wd, kmax = args.batch, args.height, args.width, args.kmax
     frames = W.synthetic_frames(args.frames, 1000 + rank * B, B, H, Wd)
     d_frames = torch.from_numpy(frames).to(dev)
-    sd_dc = calibrate_dustbin(W.synthetic_state_dict("detector", 1234), d_frames, dev)
+    # every rank calibrates on the SAME frames (rank 0's), so all ranks run identical weights
+    calib = d_frames if rank == 0 else torch.from_numpy(W.synthetic_frames(args.frames, 1000, B, H, Wd)).to(dev)
+    sd_dc = calibrate_dustbin(W.synthetic_state_dict("detector", 1234), calib, dev)
+    del calib
     sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
 
     n_i32 = B + B * kmax * 6
     out_dev = torch.empty((n_i32,), dtype=torch.int32, device=dev)
     host_local = torch.empty((n_i32,), dtype=torch.int32).pin_memory()
-    host_all = torch.empty((world, n_i32), dtype=torch.int32).pin_memory() if world > 1 else None
+    host_all = torch.empty((world, n_i32), dtype=torch.int32).pin_memory() if world > 1 else None   # every rank (gloo mode fills it everywhere)
     gathered = torch.empty((world, n_i32), dtype=torch.int32, device=dev) if world > 1 else None
 
     def step():
         packed = infer_batch_device(d_frames, 16, dc, rn, kmax, out=out_dev)
-        if world > 1:   # the path's only exchange step: one fused all-gather of the corner lists
+        if world > 1 and args.backend == "nccl":   # the path's only exchange step: one fused all-gather of the corner lists
             dist.all_gather_into_tensor(gathered.view(-1), packed)
             if rank == 0:
                 host_all.copy_(gathered, non_blocking=True)
+        elif world > 1:                             # gloo smoke mode: exchange through host memory
+            dist.all_gather_into_tensor(host_all.view(-1), packed.cpu())
         else:
             host_local.copy_(packed, non_blocking=True)
 
@@ -184,19 +198,19 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- what the timed steps produced
+    # ---- what the timed steps produced (outside the timed region)
+    local_counts = unpack_results(out_dev.cpu().numpy(), B, kmax, True)[1]
     if world > 1 and rank == 0:
-        res_counts = [unpack_results(host_all[r].numpy(), B, kmax, True)[1] for r in range(world)]
-        counts = np.concatenate(res_counts)
+        counts = np.concatenate([unpack_results(host_all[r].numpy(), B, kmax, True)[1] for r in range(world)])
     else:
-        counts = unpack_results(host_local.numpy(), B, kmax, True)[1]
+        counts = local_counts
     mean_k = float(np.minimum(counts, kmax).mean())
     overflow = int((counts > kmax).sum())
-    total_patches = float(np.minimum(counts[:B], kmax).sum()) if len(counts) >= B else 0.0
+    total_patches = float(np.minimum(local_counts, kmax).sum())
 
     # ---- roofline of the dominant kernel: its launches inside the timed region, hipEvent-bracketed on the
     # stream they run on; the per-kernel table comes from 3 extra, fully bracketed steps after the timed region

@@ -3,6 +3,19 @@ from __future__ import annotations
 
 import numpy as np
 
+_cv2 = None          # resolved once: the module, or False when OpenCV is not installed
+
+
+def _opencv():
+    global _cv2
+    if _cv2 is None:
+        try:
+            import cv2  # type: ignore
+            _cv2 = cv2
+        except ImportError:
+            _cv2 = False
+    return _cv2
+
 
 def bgr2gray(img_bgr: np.ndarray) -> np.ndarray:
     """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) (call site /root/reference/src/inference.py:40).
@@ -10,14 +23,14 @@ def bgr2gray(img_bgr: np.ndarray) -> np.ndarray:
     Uses OpenCV when it is importable; otherwise OpenCV's published 8-bit fixed-point formula
     gray = (1868*B + 9617*G + 4899*R + 8192) >> 14.
     """
-    try:
-        import cv2  # type: ignore
+    cv2 = _opencv()
+    if cv2:
         return cv2.cvtColor(img_bgr, cv2.COLOR_BGR2GRAY)
-    except ImportError:
-        pass
     if img_bgr.ndim != 3 or img_bgr.shape[2] != 3 or img_bgr.dtype != np.uint8:
         raise ValueError("expected a (H,W,3) uint8 BGR image")
-    b = img_bgr[..., 0].astype(np.int32)
-    g = img_bgr[..., 1].astype(np.int32)
-    r = img_bgr[..., 2].astype(np.int32)
-    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+    acc = img_bgr[..., 0].astype(np.uint32) * np.uint32(1868)
+    acc += img_bgr[..., 1].astype(np.uint32) * np.uint32(9617)
+    acc += img_bgr[..., 2].astype(np.uint32) * np.uint32(4899)
+    acc += np.uint32(8192)
+    acc >>= np.uint32(14)
+    return acc.astype(np.uint8)
