@@ -1,0 +1,89 @@
+"""Asynchronous, double-buffered caller of the batch path.
+
+The reference's callers feed one frame at a time and block on every stage
+(/root/reference/src/pose_estimation.py:52-89, src/benchmark.py:45-53).  ``FrameStream`` keeps
+``depth`` batches in flight: while batch i runs the HIP pipeline on the compute stream, batch i+1 is
+copied host->device from pinned memory on a copy stream and batch i-1's packed corner list is
+copied back; the host only ever waits on the oldest batch's completion event.  Results are the same
+arrays ``infer_batch`` returns (frames are independent).
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, unpack_results
+from .sharding import packed_len
+
+
+class FrameStream:
+    def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 32, height: int = 240,
+                 width: int = 320, kmax: int = DEFAULT_KMAX, depth: int = 2):
+        det = deepc.model if hasattr(deepc, "model") else deepc
+        self.dev = det.device
+        self.dust_bin_ids, self.deepc, self.refinenet = dust_bin_ids, deepc, refinenet
+        self.batch, self.h, self.w, self.kmax, self.depth = batch, height, width, kmax, depth
+        n_out = packed_len(batch, kmax)
+        with torch.cuda.device(self.dev):
+            self.copy_stream = torch.cuda.Stream()
+            self.pin_in = [torch.empty((batch, height, width), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+            self.dev_in = [torch.empty((batch, height, width), dtype=torch.uint8, device=self.dev) for _ in range(depth)]
+            self.dev_out = [torch.empty((n_out,), dtype=torch.int32, device=self.dev) for _ in range(depth)]
+            self.pin_out = [torch.empty((n_out,), dtype=torch.int32).pin_memory() for _ in range(depth)]
+            self.ev_h2d = [torch.cuda.Event() for _ in range(depth)]
+            self.ev_free = [torch.cuda.Event() for _ in range(depth)]     # compute finished reading dev_in[s]
+            self.ev_done = [torch.cuda.Event() for _ in range(depth)]
+        self._pending: List[Optional[Tuple[int, int, np.ndarray]]] = [None] * depth   # (ticket, n_frames, host frames)
+        self._ticket = 0
+
+    def _collect(self, slot: int):
+        ticket, n, frames = self._pending[slot]
+        self._pending[slot] = None
+        self.ev_done[slot].synchronize()
+        res, counts = unpack_results(self.pin_out[slot].numpy(), self.batch, self.kmax, self.refinenet is not None)
+        res = res[:n]
+        if n and int(counts[:n].max()) > self.kmax:      # rare: a frame exceeded the capacity -> exact re-run
+            res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, kmax=self.kmax)
+        return ticket, res
+
+    def submit(self, frames_gray: np.ndarray):
+        """Enqueue one batch (n <= batch frames). Returns the (ticket, results) of the batch that had to be
+        retired to make room, or None."""
+        n = frames_gray.shape[0]
+        if n > self.batch or tuple(frames_gray.shape[1:]) != (self.h, self.w) or frames_gray.dtype != np.uint8:
+            raise ValueError("frames must be (n<=batch, H, W) uint8")
+        slot = self._ticket % self.depth
+        retired = self._collect(slot) if self._pending[slot] is not None else None
+        self.pin_in[slot][:n].numpy()[...] = frames_gray
+        if n < self.batch:
+            self.pin_in[slot][n:].zero_()
+        with torch.cuda.device(self.dev):
+            compute = torch.cuda.current_stream()
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(self.ev_free[slot])         # previous user of dev_in[slot] is done
+                self.dev_in[slot].copy_(self.pin_in[slot], non_blocking=True)
+                self.ev_h2d[slot].record(self.copy_stream)
+            compute.wait_event(self.ev_h2d[slot])
+            infer_batch_device(self.dev_in[slot], self.dust_bin_ids, self.deepc, self.refinenet, self.kmax,
+                               out=self.dev_out[slot])
+            self.ev_free[slot].record(compute)
+            self.pin_out[slot].copy_(self.dev_out[slot], non_blocking=True)
+            self.ev_done[slot].record(compute)
+        self._pending[slot] = (self._ticket, n, frames_gray)
+        self._ticket += 1
+        return retired
+
+    def flush(self) -> Iterator[Tuple[int, List[np.ndarray]]]:
+        order = sorted((p[0], s) for s, p in enumerate(self._pending) if p is not None)
+        for _, slot in order:
+            yield self._collect(slot)
+
+    def run(self, batches: Iterable[np.ndarray]) -> Iterator[Tuple[int, List[np.ndarray]]]:
+        """batches: iterable of (n,H,W) uint8 arrays -> (ticket, per-frame keypoint arrays) in submission order."""
+        for fr in batches:
+            r = self.submit(fr)
+            if r is not None:
+                yield r
+        yield from self.flush()

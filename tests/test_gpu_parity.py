@@ -443,3 +443,76 @@ def test_config5_resolution_1280x960(dev):
     for b in range(2):
         exp = O.infer_image(None, 16, t_dc, t_rn, gray=frames[b])
         assert res[b].shape == exp.shape and np.array_equal(res[b], exp), f"frame {b}"
+
+
+@pytest.mark.parametrize("n_ids", [8, 24])
+def test_other_board_sizes_n_ids(dev, n_ids):
+    """n_ids = (rows-1)*(cols-1) is a model parameter (configs.py:34-35): 3x5 and 5x7 boards, not only 16."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 40 + n_ids, 2, 120, 160)
+    sd_dc = _calibrated(300 + n_ids, frames, n_ids=n_ids, target_per_frame=10)
+    sd_rn = W.synthetic_state_dict("refinenet", 7)
+    dc, rn = lModel(dcModel(n_ids, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    loc, ids = dc.infer_image(torch.tensor(O.pre_bgr_image(frames[0])).to(dev))
+    assert ids.shape == (1, n_ids + 1, 15, 20)
+    o_loc, o_ids = O.detector_infer_image(O.to_torch_state_dict(sd_dc), torch.tensor(O.pre_bgr_image(frames[0])))
+    assert (ids.cpu() - o_ids).abs().max() <= LOGIT_ATOL and (loc.cpu() - o_loc).abs().max() <= LOGIT_ATOL
+    got = infer_batch(frames, n_ids, dc, rn)
+    for b in range(2):
+        exp = O.infer_image(None, n_ids, O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn), gray=frames[b])
+        assert got[b].shape == exp.shape and np.array_equal(got[b], exp)
+
+
+def test_c_abi_error_codes(dev, golden_tiny):
+    """Argument / shape / workspace errors come back as negative DCX_E_* codes, never as a crash."""
+    import ctypes as C
+    from deepcharuco_amd import _lib
+    from deepcharuco_amd.models.net import dcModel
+    L = _lib.lib()
+    det = dcModel(16, golden_tiny.sd_dc, dev)
+    frames = torch.zeros((1, 64, 96), dtype=torch.uint8, device=dev)
+    ws = torch.empty(L.dcx_detector_workspace_bytes(det.handle, 1, 64, 96), dtype=torch.uint8, device=dev)
+    ok = L.dcx_detector_forward(det.handle, frames.data_ptr(), 64 * 96, 96, None, 1, 64, 96, ws.data_ptr(), ws.numel(),
+                                None, None, None)
+    assert ok == 0
+    torch.cuda.synchronize()
+    assert L.dcx_detector_forward(det.handle, frames.data_ptr(), 60 * 96, 96, None, 1, 60, 96, ws.data_ptr(),
+                                  ws.numel(), None, None, None) == -2                     # H not a multiple of 8
+    assert L.dcx_detector_forward(det.handle, frames.data_ptr(), 64 * 96, 96, None, 1, 64, 96, ws.data_ptr(), 1024,
+                                  None, None, None) == -3                                 # workspace too small
+    assert L.dcx_detector_forward(det.handle, None, 0, 0, None, 1, 64, 96, ws.data_ptr(), ws.numel(),
+                                  None, None, None) == -1                                 # no input at all
+    h = C.c_void_p()
+    arr = (C.c_void_p * 64)()
+    assert L.dcx_detector_create(C.byref(h), arr, 64, 16) == -1                           # null tensors
+    assert L.dcx_detector_create(C.byref(h), arr, 63, 16) == -1                           # wrong tensor count
+    with pytest.raises(_lib.DcxError, match="DCX_E_SHAPE"):
+        det.forward(torch.zeros((1, 1, 60, 96), device=dev))
+    from deepcharuco_amd.models.refinenet import RefineNet
+    rn = RefineNet(golden_tiny.sd_rn, dev)
+    with pytest.raises(ValueError):
+        rn.forward(torch.zeros((2, 1, 20, 24), device=dev))
+    with pytest.raises(AssertionError):
+        rn.infer_patches(torch.zeros((2, 20, 24), device=dev), torch.zeros((2, 2), dtype=torch.int64, device=dev))
+    assert rn.infer_patches(torch.zeros((0, 24, 24), device=dev), torch.zeros((0, 2), dtype=torch.int64, device=dev))[1].shape == (0, 2)
+
+
+def test_frame_stream_matches_infer_batch(dev):
+    """The double-buffered asynchronous caller returns, in order, exactly what infer_batch returns
+    (ragged last batch, more batches than slots)."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.stream import FrameStream
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 700, 22, 120, 160)
+    sd_dc = _calibrated(55, frames[:4])
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 56), dev))
+    ref = infer_batch(frames, 16, dc, rn)
+    fs = FrameStream(16, dc, rn, batch=4, height=120, width=160, kmax=64, depth=2)
+    chunks = [frames[i:i + 4] for i in range(0, 22, 4)]       # 5 full batches + one of 2 frames
+    out = list(fs.run(chunks))
+    assert [t for t, _ in out] == list(range(6))
+    flat = [a for _, res in out for a in res]
+    assert len(flat) == 22 and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, ref))
