@@ -62,7 +62,9 @@ struct DcxConvCfg {
     static constexpr int OCC_LDS = (LDS_BYTES * 3 <= 160 * 1024) ? 3 : ((LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1);
     // 2 workgroups/CU measured best for 64-register accumulators (256 registers per lane); the big wave tiles
     // (128 accumulator registers) run one workgroup per CU with the whole 512-register file
-    static constexpr int OCC = (MT * NT * 16 > 64) ? 1 : (OCC_LDS > 2 ? 2 : OCC_LDS);
+    static constexpr int OCC = (MT * NT * 16 > 64) ? 1
+                             : (MT * NT * 16 <= 16) ? (OCC_LDS > 3 ? 3 : OCC_LDS)   // small tiles: more workgroups hide the barriers
+                             : (OCC_LDS > 2 ? 2 : OCC_LDS);
     static_assert(TILE_PIX <= CAP, "tile does not fit the wave layout");
     static_assert(!POOL || (TH % 2 == 0 && TW % 2 == 0), "pooled tiles must be even");
     static_assert(EPI != DCX_EPI_HEAT || (WM == 1 && !POOL), "heat epilogue needs all couts in one wave row");

@@ -7,13 +7,13 @@
 namespace {
 
 struct CfgEntry {
-    int cout_tile, cap, th, tw, ks, pool, epi;
+    int cout_tile, cap, th, tw, ks, pool, epi, acc_tiles;
     int (*launch)(DcxConvArgs, hipStream_t);
     const char* name;
 };
 
 #define DCX_CFG(WM, WN, MT, NT, TH, TW, KS, POOL, EPI)                                              \
-    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI,                                             \
+    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT,                                           \
       &dcx_conv_launch_cfg<DcxConvCfg<WM, WN, MT, NT, TH, TW, KS, (POOL) != 0, EPI>>,                 \
       "dcx_conv_mfma_kernel<DcxConvCfg<" #WM "," #WN "," #MT "," #NT "," #TH "," #TW "," #KS "," #POOL "," #EPI ">>" }
 
@@ -30,6 +30,7 @@ const CfgEntry kCfgs[] = {
     DCX_CFG(2, 2, 2, 2, 6, 18, 3, 0, DCX_EPI_BNRELU),
     DCX_CFG(2, 2, 2, 2, 8, 16, 3, 0, DCX_EPI_BNRELU),
     DCX_CFG(4, 1, 1, 2, 8, 8, 3, 0, DCX_EPI_BNRELU),
+    DCX_CFG(2, 2, 1, 1, 8, 8, 3, 0, DCX_EPI_BNRELU),     // S: 64 cout x 64 px, 32x32 per wave (small batches / small maps)
     // 3x3 + BN + ReLU + 2x2 max-pool
     DCX_CFG(1, 4, 2, 4, 16, 32, 3, 1, DCX_EPI_BNRELU),
     DCX_CFG(1, 4, 2, 2, 8, 32, 3, 1, DCX_EPI_BNRELU),
@@ -37,6 +38,7 @@ const CfgEntry kCfgs[] = {
     DCX_CFG(1, 4, 2, 2, 6, 40, 3, 1, DCX_EPI_BNRELU),
     DCX_CFG(1, 4, 2, 2, 16, 16, 3, 1, DCX_EPI_BNRELU),
     DCX_CFG(2, 2, 2, 2, 8, 16, 3, 1, DCX_EPI_BNRELU),
+    DCX_CFG(2, 2, 1, 1, 8, 8, 3, 1, DCX_EPI_BNRELU),
     // 1x1, raw (image flattened to 1 x P by the caller)
     DCX_CFG(1, 4, 2, 2, 1, 256, 1, 0, DCX_EPI_RAW),
     // RefineNet head: 3x3 + BN + ReLU + 1x1 -> 1 channel + tile arg-max
@@ -50,25 +52,37 @@ int dcx_big_tiles_disabled() {
     return v;
 }
 
-const CfgEntry* pick(int ho, int wo, int cout_pad, int ks, int pool, int epi) {
+// Tile choice = argmin of a small cost model (cycles on the busiest CU), calibrated with the in-kernel probes
+// (tools/unit_probe.py):  rounds = ceil(items / #CU) work items run one after the other on a CU (co-resident
+// workgroups share its FMA pipes), each costing its MFMA cycles -- padded pixels included, so tile utilisation is
+// accounted for -- plus ~520 cycles per 16-channel unit (barrier, first LDS wait, scalar bookkeeping) and an epilogue
+// of ~40 (60 pooled) cycles per accumulator register.  Big tiles win when there is plenty of work (less halo, fewer
+// units), the 64x64 S tile when a launch has few items (bs=1, 30x40 maps) or would leave CUs idle in the last round.
+const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int pool, int epi) {
     const CfgEntry* best = nullptr;
-    double best_score = -1.0;
+    double best_cost = 0.0;
+    const int n_cu = dcx_device_cu_count();
     for (const CfgEntry& c : kCfgs) {
         if (c.ks != ks || c.pool != pool || c.epi != epi) continue;
         if (cout_pad % c.cout_tile != 0) continue;
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
-        double score = (double)ho * wo / ((double)tiles * c.cap);   // useful fraction of the MFMA work
-        if (c.cap > 256 && (dcx_big_tiles_disabled() || score < 0.999)) continue;   // big tiles only on an exact fit
-        // mild preference for the 64-cout layout (smaller halo re-read per flop) on ties
-        if (c.cout_tile == 64) score += 1e-6;
-        if (score > best_score) { best_score = score; best = &c; }
+        if (c.cap > 256 && (dcx_big_tiles_disabled() || (double)ho * wo / ((double)tiles * c.cap) < 0.999)) continue;
+        const double items = (double)n * (cout_pad / c.cout_tile) * tiles;
+        const int units = cin / DCX_CCH;
+        const int steps = ks * ks * (DCX_CCH / 8);
+        const double item_cost = (double)units * steps * (4 * c.acc_tiles) * 64.0 + units * 520.0
+                               + c.acc_tiles * 16 * (pool ? 60.0 : 40.0);
+        const double rounds = (double)(((long)items + n_cu - 1) / n_cu);
+        double cost = rounds * item_cost;
+        if (c.cout_tile == 64 && c.cap == 256) cost *= 0.999;   // deterministic tie-break towards the A layout
+        if (best == nullptr || cost < best_cost) { best_cost = cost; best = &c; }
     }
     return best;
 }
 
 // ---- per-launch profiling ---------------------------------------------------------------------
 struct ProfRec { int kernel_id, n, limited; double flops_per_image; hipEvent_t e0, e1; int slot; };
-unsigned long long* g_clk_dev = nullptr;   // [kClkSlots][4] shader-clock probes of workgroup 0
+unsigned long long* g_clk_dev = nullptr;   // [kClkSlots][kClkWords] shader-clock probes of workgroup 0
 constexpr int kClkSlots = 1024;
 constexpr int kClkWords = 64;   // per launch: 4 clock words + 3 timestamps per unit for the first 20 units
 bool g_prof = false;
@@ -159,7 +173,7 @@ int dcx_occupancy_override() {
 }
 
 int dcx_conv_heat_tiles(int ho, int wo) {
-    const CfgEntry* c = pick(ho, wo, 64, 3, 0, DCX_EPI_HEAT);
+    const CfgEntry* c = pick(1 << 20, 64, ho, wo, 64, 3, 0, DCX_EPI_HEAT);
     return c ? ((ho + c->th - 1) / c->th) * ((wo + c->tw - 1) / c->tw) : 0;
 }
 
@@ -168,7 +182,7 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
     if (epi != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
     if (epi != DCX_EPI_RAW && (a.alpha == nullptr || a.beta == nullptr)) return DCX_E_ARG;
     if (pool && ((a.ho | a.wo) & 1)) return DCX_E_SHAPE;
-    const CfgEntry* c = pick(a.ho, a.wo, a.cout_pad, ks, pool, epi);
+    const CfgEntry* c = pick(a.n, a.cin, a.ho, a.wo, a.cout_pad, ks, pool, epi);
     if (c == nullptr) return DCX_E_SHAPE;
     if (!g_prof || (g_prof_filter >= 0 && g_prof_filter != (int)(c - kCfgs))) return c->launch(a, stream);
     ProfRec r;
