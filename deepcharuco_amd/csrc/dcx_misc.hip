@@ -105,6 +105,7 @@ __device__ __forceinline__ float dcx_logit(const DcxLogitView& v, int b, int c, 
     return v.p[(size_t)b * v.sb + (size_t)(c >> 2) * v.sq + (size_t)cell * v.sp + (size_t)(c & 3) * v.sc];
 }
 
+template <bool C4>
 __global__ __launch_bounds__(256) void dcx_decode_kernel(DcxLogitView loc, DcxLogitView ids, int n_loc, int n_ids1,
                                                            int hc, int wc, int dust_bin, int kmax,
                                                            int32_t* __restrict__ counts, int32_t* __restrict__ rows,
@@ -122,15 +123,39 @@ __global__ __launch_bounds__(256) void dcx_decode_kernel(DcxLogitView loc, DcxLo
         bool fire = false;
         int la = 0, ia = 0;
         if (cell < cells) {
-            float best = dcx_logit(loc, b, 0, cell);
-            for (int c = 1; c < n_loc; ++c) {            // torch.argmax: first maximum wins
-                const float v = dcx_logit(loc, b, c, cell);
-                if (v > best) { best = v; la = c; }
-            }
-            best = dcx_logit(ids, b, 0, cell);
-            for (int c = 1; c < n_ids1; ++c) {
-                const float v = dcx_logit(ids, b, c, cell);
-                if (v > best) { best = v; ia = c; }
+            if (C4) {
+                // C4 logits [b][quad][cell][4]: one 16-B load per channel quad, lanes on consecutive cells.
+                // Channels are visited in increasing order with a strict '>' so the first maximum wins
+                // (torch.argmax); the zero-filled pad channels of the last quad are never looked at.
+                const float4* lq = reinterpret_cast<const float4*>(loc.p) + (size_t)b * (loc.sb >> 2) + cell;
+                const float4* iq = reinterpret_cast<const float4*>(ids.p) + (size_t)b * (ids.sb >> 2) + cell;
+                float best = -INFINITY;
+                for (int q = 0; 4 * q < n_loc; ++q) {
+                    const float4 v = lq[(size_t)q * cells];
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * q + k < n_loc && (e[k] > best || (q == 0 && k == 0))) { best = e[k]; la = 4 * q + k; }
+                }
+                best = -INFINITY;
+                for (int q = 0; 4 * q < n_ids1; ++q) {
+                    const float4 v = iq[(size_t)q * cells];
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * q + k < n_ids1 && (e[k] > best || (q == 0 && k == 0))) { best = e[k]; ia = 4 * q + k; }
+                }
+            } else {
+                float best = dcx_logit(loc, b, 0, cell);
+                for (int c = 1; c < n_loc; ++c) {            // torch.argmax: first maximum wins
+                    const float v = dcx_logit(loc, b, c, cell);
+                    if (v > best) { best = v; la = c; }
+                }
+                best = dcx_logit(ids, b, 0, cell);
+                for (int c = 1; c < n_ids1; ++c) {
+                    const float v = dcx_logit(ids, b, c, cell);
+                    if (v > best) { best = v; ia = c; }
+                }
             }
             if (la == n_loc - 1) ia = dust_bin;          // where(loc_argmax == 64, dust_bin, ids_argmax)
             fire = ia != dust_bin;
@@ -168,8 +193,14 @@ int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, 
                       int32_t* loc_argmax, int32_t* ids_argmax, hipStream_t s) {
     if (!loc.p || !ids.p || !counts || !rows) return DCX_E_ARG;
     if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0 || n_loc != 65 || n_ids1 < 2) return DCX_E_SHAPE;
-    hipLaunchKernelGGL(dcx_decode_kernel, dim3((unsigned)batch), dim3(256), 0, s, loc, ids, n_loc, n_ids1, hc, wc,
-                       dust_bin, kmax, counts, rows, loc_argmax, ids_argmax);
+    const bool c4 = loc.sc == 1 && loc.sp == 4 && ids.sc == 1 && ids.sp == 4 && loc.sq == 4L * hc * wc && ids.sq == 4L * hc * wc
+                    && (loc.sb & 3) == 0 && (ids.sb & 3) == 0;
+    if (c4)
+        hipLaunchKernelGGL(dcx_decode_kernel<true>, dim3((unsigned)batch), dim3(256), 0, s, loc, ids, n_loc, n_ids1, hc, wc,
+                           dust_bin, kmax, counts, rows, loc_argmax, ids_argmax);
+    else
+        hipLaunchKernelGGL(dcx_decode_kernel<false>, dim3((unsigned)batch), dim3(256), 0, s, loc, ids, n_loc, n_ids1, hc, wc,
+                           dust_bin, kmax, counts, rows, loc_argmax, ids_argmax);
     return (int)hipGetLastError();
 }
 
