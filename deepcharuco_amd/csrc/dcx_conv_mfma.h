@@ -11,11 +11,11 @@
 //   D lane l holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r = 0..15.
 //   => a lane owns ONE pixel and, per accumulator, four groups of 4 consecutive couts: exactly one
 //      float4 of the C4 layout [N][C/4][H][W][4], so epilogue stores are 16 B per lane and 512 B
-//      contiguous per half-wave, and the 2x2 max-pool is two DPP-style lane exchanges.
+//      contiguous per half-wave, and the 2x2 max-pool is two v_max_f32_dpp quad_perm per value.
 //
 // Both operands are fetched as float4 = 4 consecutive cin of one cout / one pixel:
 //   lane (half = l>>5) reads channel quad (2s + half) of an 8-channel group s, register j of the
-//   float4 feeds MFMA j, so one ds_read_b128 + one global_load_dwordx4 per tile feed 4 MFMAs
+//   float4 feeds MFMA j, so one ds_read_b128 + one buffer_load_dwordx4 per tile feed 4 MFMAs
 //   (256 cycles).  The resulting summation order is specified (and restated bit-exactly by
 //   oracle/conv_exact.c):
 //     acc = 0;  for chunk c (16 cin) / tap (dy-major) / s in 0..1 / j in 0..3:
@@ -23,12 +23,18 @@
 //                  acc = fmaf(w[8s+4+j], x[8s+4+j], acc);     (k = 1 half)
 //   i.e. an exact sequential fp32 fmaf chain (MFMA f32 numerics, cdna_hip_programming.md section 3).
 //
-// Activations: the (TH+2)x(TW+2) input halo tile of a 32-channel chunk is staged in LDS as
-//   sB[buf][cq][halo_pixel] float4 (double buffered, 16-channel chunks) -- consecutive lanes read consecutive 16-B slots (conflict-free
-//   ds_read_b128 without padding or swizzle).  Zero padding, the valid-conv offset and the nearest
-//   x2 up-sampling of RefineNet are all resolved while staging, so the MFMA loop is identical for
-//   every layer.  Weights ([tap][cin/4][cout][4], <= 1.2 MB, L2 resident) are streamed straight
-//   from L2 into registers one step ahead of use; the 4 waves of a workgroup share them through L1.
+// Activations: the (TH+2)x(TW+2) input halo tile of a 16-channel chunk is staged in LDS as
+//   sB[buf][cq][halo_pixel] float4 (double buffered) -- consecutive lanes read consecutive 16-B slots
+//   (conflict-free ds_read_b128 without padding or swizzle).  Zero padding, the valid-conv offset and the
+//   nearest x2 up-sampling of RefineNet are all resolved while staging (buffer loads: per-piece constant
+//   voffset relative to the tile origin, hardware out-of-range -> 0.0f), so the MFMA loop is identical for
+//   every layer.  Weights ([tap][cin/4][cout][4], <= 1.2 MB, L2 resident) are streamed from L2 into
+//   registers two k-steps ahead of use (buffer loads: per-lane constant voffset, uniform soffset).
+//
+// Measured on gfx950 (tools/ubench/mfma_fill.hip): every VALU instruction issued between these MFMAs costs
+//   its full ~8 cycles -- the f32 MFMA runs on the vector FMA datapath -- while memory, LDS, scalar
+//   instructions and s_nop are free.  The k-loop therefore contains (almost) no VALU instruction, and the
+//   epilogue is written for minimum VALU count (packed FMA, fused DPP max).  See DESIGN.md section 3.1.
 #pragma once
 #include "dcx_common.h"
 
