@@ -69,6 +69,7 @@ SIGNATURES = {
     "dcx_c4_to_nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dcx_set_timing": (_i, [_i]),
     "dcx_last_timings": (_i, [C.POINTER(C.c_float)]),
+    "dcx_conv_pick_name": (C.c_char_p, [_i] * 8),
     "dcx_profile_enable": (_i, [_i]),
     "dcx_profile_count": (_i, []),
     "dcx_profile_filter": (_i, [_i]),

@@ -102,6 +102,12 @@ hipEvent_t prof_event() {
 
 }  // namespace
 
+// which instantiation the cost model picks for a launch shape (no GPU needed; used by tests and tools)
+extern "C" const char* dcx_conv_pick_name(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi) {
+    const CfgEntry* c = pick(n, cin, ho, wo, dcx_conv_cout_pad(cout), ks, pool, epi);
+    return c ? c->name : "";
+}
+
 extern "C" int dcx_profile_enable(int enabled) {
     g_prof = enabled != 0;
     if (g_prof) { g_recs.clear(); g_pool_used = 0; }

@@ -161,6 +161,10 @@ int dcx_c4_to_nchw(const float* d_c4, int n, int c, int h, int w, float* d_nchw,
 int dcx_set_timing(int enabled);
 int dcx_last_timings(float* h_ms4);
 
+/* name of the kernel instantiation the tile cost model selects for a launch shape (host only, no GPU needed);
+ * epi: 0 = BN+ReLU, 1 = raw (1x1 heads), 2 = RefineNet head; "" when no instantiation fits */
+const char* dcx_conv_pick_name(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi);
+
 /* ---- instrumentation: per-launch profile of the MFMA convolution kernel (roofline) ---------
  * While enabled, every launch of the convolution kernel is bracketed by two hipEvents on its
  * stream and recorded.  dcx_profile_enable(1) clears the record list.  After the caller has

@@ -121,3 +121,52 @@ def test_shard_range_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_tile_cost_model_choices():
+    """The host-side tile selection (csrc/dcx_conv_mfma.hip: pick) is a cost model; these are the choices the
+    design relies on: big 64x256 tiles when a launch has plenty of work, the 64x64 S tile when it has few items."""
+    from deepcharuco_amd import _lib
+    L = _lib.lib()
+    name = lambda *a: L.dcx_conv_pick_name(*a).decode()
+    A_POOL = "dcx_conv_mfma_kernel<DcxConvCfg<1,4,2,2,8,32,3,1,DCX_EPI_BNRELU>>"
+    assert name(32, 64, 240, 320, 64, 3, 1, 0) == A_POOL                       # conv1b, bs=32
+    assert name(128, 64, 480, 640, 64, 3, 1, 0) == A_POOL                      # conv1b, cfg3
+    assert "<1,4,2,2,8,32,3,0,DCX_EPI_BNRELU>" in name(32, 64, 120, 160, 64, 3, 0, 0)    # conv2a
+    assert "<2,2,1,1,8,8,3,0,DCX_EPI_BNRELU>" in name(32, 128, 30, 40, 128, 3, 0, 0)     # conv4a bs=32: 320 big items -> S
+    assert "<2,2,1,1,8,8,3,0,DCX_EPI_BNRELU>" in name(1, 128, 30, 40, 128, 3, 0, 0)      # bs=1
+    assert "<2,2,1,1,8,8,3,1,DCX_EPI_BNRELU>" in name(1, 64, 240, 320, 64, 3, 1, 0)      # conv1b bs=1
+    assert "DCX_EPI_HEAT" in name(512, 64, 64, 64, 64, 3, 0, 2)
+    assert "<1,4,2,2,1,256,1,0,DCX_EPI_RAW>" in name(32, 256, 1, 1200, 65, 1, 0, 1)
+    assert name(32, 64, 30, 40, 64, 3, 0, 1) == ""                              # no raw 3x3 instantiation
+
+
+def test_c_restatement_agrees_with_torch_fp32():
+    """oracle/conv_exact.c (the bit-exact checker of the MFMA kernel) is itself checked against torch's fp32 conv
+    on CPU: same maths, different summation order -> equal within fp32 re-ordering noise."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.conv_exact import conv_exact
+    g = torch.Generator().manual_seed(5)
+    for cin, cout, h, w, pad, ups, pool, ks, has_bn in [(64, 64, 12, 20, 1, False, True, 3, True),
+                                                         (32, 48, 9, 7, 0, False, False, 3, True),
+                                                         (64, 32, 5, 6, 1, True, False, 3, True),
+                                                         (64, 17, 4, 5, 0, False, False, 1, False),
+                                                         (1, 64, 10, 12, 1, False, False, 3, True)]:
+        x = torch.randn(2, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        bn = None
+        if has_bn:
+            bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+                  torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+        got = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
+                         pad=pad, ups=ups, pool=pool)
+        xr = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        ref = F.conv2d(xr, wt, b, padding=pad)
+        if bn is not None:
+            ref = F.relu(F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5))
+        if pool:
+            ref = F.max_pool2d(ref, 2, 2)
+        assert got.shape == tuple(ref.shape)
+        assert np.abs(got - ref.numpy()).max() <= 2e-5
