@@ -99,19 +99,16 @@ __device__ __forceinline__ float4 dcx_fma4(float4 x, float4 al, float4 be) {
     const dcx_f32x2 hi = __builtin_elementwise_fma(dcx_f32x2{x.z, x.w}, dcx_f32x2{al.z, al.w}, dcx_f32x2{be.z, be.w});
     return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
-// max(x, quad_perm(x)) in ONE VALU instruction (v_max_f32 with a DPP source).  The s_nop covers the
-// "VALU write -> DPP read" hazard, which hipcc does not pad inside an asm statement.
-#define DCX_MAX_DPP(x, PERM) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "+v"(x))
-__device__ __forceinline__ float4 dcx_quad_max_fused(float4 v) {   // max over the 4 lanes of a quad
+// ReLU + 2x2 max-pool of one float4 as 12 VALU instructions (v_max_f32 with a DPP source = exchange + max in one)
+// and NO s_nop: the "VALU write -> DPP read" hazard needs 2 wait states, which hipcc does not pad inside asm.  All 12
+// statements are volatile (their order is kept) and each DPP reads a register written >= 3 instructions earlier
+// (x, y, z, w round-robin), so the distance holds by construction.  quad_perm [1,0,3,2] = lane^1, [2,3,0,1] = lane^2.
+#define DCX_VMAX0(x) asm volatile("v_max_f32 %0, 0, %0" : "+v"(x))
+#define DCX_MAX_DPP(x, PERM) asm volatile("v_max_f32_dpp %0, %0, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "+v"(x))
+__device__ __forceinline__ float4 dcx_relu_quad_max(float4 v) {
+    DCX_VMAX0(v.x); DCX_VMAX0(v.y); DCX_VMAX0(v.z); DCX_VMAX0(v.w);
     DCX_MAX_DPP(v.x, "[1,0,3,2]"); DCX_MAX_DPP(v.y, "[1,0,3,2]"); DCX_MAX_DPP(v.z, "[1,0,3,2]"); DCX_MAX_DPP(v.w, "[1,0,3,2]");
     DCX_MAX_DPP(v.x, "[2,3,0,1]"); DCX_MAX_DPP(v.y, "[2,3,0,1]"); DCX_MAX_DPP(v.z, "[2,3,0,1]"); DCX_MAX_DPP(v.w, "[2,3,0,1]");
-    return v;
-}
-__device__ __forceinline__ float4 dcx_quad_max(float4 v) {   // max over the 4 lanes of a quad (2x2 pooling window)
-    v.x = dcx_vmax(v.x, dcx_quad_perm<0xB1>(v.x)); v.y = dcx_vmax(v.y, dcx_quad_perm<0xB1>(v.y));
-    v.z = dcx_vmax(v.z, dcx_quad_perm<0xB1>(v.z)); v.w = dcx_vmax(v.w, dcx_quad_perm<0xB1>(v.w));
-    v.x = dcx_vmax(v.x, dcx_quad_perm<0x4E>(v.x)); v.y = dcx_vmax(v.y, dcx_quad_perm<0x4E>(v.y));
-    v.z = dcx_vmax(v.z, dcx_quad_perm<0x4E>(v.z)); v.w = dcx_vmax(v.w, dcx_quad_perm<0x4E>(v.w));
     return v;
 }
 
@@ -375,7 +372,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                     const float4 av4 = aq[step][mt], bv4 = bq[step][nt];
                     const float av = j == 0 ? av4.x : j == 1 ? av4.y : j == 2 ? av4.z : av4.w;
                     const float bv = j == 0 ? bv4.x : j == 1 ? bv4.y : j == 2 ? bv4.z : bv4.w;
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0);
+                    if (step == 0 && j == 0 && c == 0) {
+                        // first MFMA of a work item on this accumulator: a zero C operand clears it for free
+                        const dcx_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, zero, 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0);
+                    }
                 }
                 ++pair;
                 __builtin_amdgcn_sched_barrier(0);
@@ -468,8 +471,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                             v.x += bi[g].x; v.y += bi[g].y; v.z += bi[g].z; v.w += bi[g].w;
                         } else {   // conv bias is folded into the BN shift: be = fma(bias, alpha, bn_beta - mean*alpha)
                             v = dcx_fma4(v, al[g], be[g]);
-                            v.x = dcx_vmax(v.x, 0.f); v.y = dcx_vmax(v.y, 0.f);
-                            v.z = dcx_vmax(v.z, 0.f); v.w = dcx_vmax(v.w, 0.f);
+                            if (C::POOL) {
+                                v = dcx_relu_quad_max(v);
+                            } else {
+                                v.x = dcx_vmax(v.x, 0.f); v.y = dcx_vmax(v.y, 0.f);
+                                v.z = dcx_vmax(v.z, 0.f); v.w = dcx_vmax(v.w, 0.f);
+                            }
                         }
                         if (C::EPI == DCX_EPI_HEAT) {
                             float h = hsum[nt];
@@ -478,7 +485,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                             hsum[nt] = h;
                             continue;
                         }
-                        if (C::POOL) v = dcx_quad_max_fused(v);
                         if (pix_ok[nt] && cq < a.cout_quads)
                             *reinterpret_cast<float4*>(obase + (size_t)((unsigned)(mt * 8 + 2 * g) * plane * 16u) + lane_off[nt]) = v;
                     }
@@ -522,12 +528,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                     a.part_idx[(size_t)n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
                 }
             }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
 
         if (!has_next) {
