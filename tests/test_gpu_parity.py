@@ -516,3 +516,63 @@ def test_frame_stream_matches_infer_batch(dev):
     assert [t for t, _ in out] == list(range(6))
     flat = [a for _, res in out for a in res]
     assert len(flat) == 22 and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, ref))
+
+
+def test_parity_128_frames_every_corner(dev):
+    """128 frames (noise + board, ragged corner counts) through the sync-free batch path vs the oracle, frame by
+    frame: every corner id, cell-derived integer position and sub-pixel xy must be identical."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = np.concatenate([W.synthetic_frames("noise", 4000, 64, 240, 320),
+                             W.synthetic_frames("board", 5000, 64, 240, 320)])
+    sd_dc = _calibrated(2024, frames[::16], target_per_frame=14)
+    sd_rn = W.synthetic_state_dict("refinenet", 2025)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    got = infer_batch(frames, 16, dc, rn, kmax=64)
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    corners = mismatched_frames = 0
+    for b in range(len(frames)):
+        exp = O.infer_image(None, 16, t_dc, t_rn, gray=frames[b])
+        corners += 0 if exp.ndim == 1 else exp.shape[0]
+        if got[b].shape != exp.shape or not np.array_equal(got[b], exp):
+            mismatched_frames += 1
+    _report("parity_128_frames", dict(frames=len(frames), corners=corners, mismatched_frames=mismatched_frames))
+    assert corners > 1000 and mismatched_frames == 0
+
+
+def test_pitched_frame_buffer_through_c_abi(dev, golden_tiny):
+    """The C ABI takes a row pitch and a frame stride: frames that are windows of a larger device buffer
+    (camera ring buffer with padding) give the same rows as dense frames."""
+    import ctypes as C
+    from deepcharuco_amd import _lib
+    from deepcharuco_amd.models.net import dcModel
+    from deepcharuco_amd.models.refinenet import RefineNet
+    L = _lib.lib()
+    det, rf = dcModel(16, golden_tiny.sd_dc, dev), RefineNet(golden_tiny.sd_rn, dev)
+    h, w, b, kmax = 64, 96, 3, 32
+    frames = W.synthetic_frames("noise", 5, b, h, w)          # frame 0 is the golden frame (seed 5)
+    pitch, fstride = 128, 128 * 70                             # padded rows, padded frames
+    big = torch.full((b * fstride + 64,), 255, dtype=torch.uint8, device=dev)
+    for i in range(b):
+        view = big[17 + i * fstride: 17 + i * fstride + h * pitch].view(h, pitch)
+        view[:, :w] = torch.from_numpy(frames[i]).to(dev)
+    nbytes = L.dcx_pipeline_workspace_bytes(det.handle, rf.handle, b, h, w, kmax)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def run(ptr, stride, pit):
+        counts = torch.zeros(b, dtype=torch.int32, device=dev)
+        rows = torch.zeros((b, kmax, 4), dtype=torch.int32, device=dev)
+        xy = torch.zeros((b, kmax, 2), dtype=torch.float32, device=dev)
+        _lib.check(L.dcx_infer_batch(det.handle, rf.handle, ptr, stride, pit, b, h, w, 16, kmax, ws.data_ptr(),
+                                     ws.numel(), counts.data_ptr(), rows.data_ptr(), xy.data_ptr(), None), "infer")
+        torch.cuda.synchronize()
+        return counts.cpu(), rows.cpu(), xy.cpu()
+    dense = torch.from_numpy(frames).to(dev)
+    c0, r0, x0 = run(dense.data_ptr(), h * w, w)
+    c1, r1, x1 = run(big.data_ptr() + 17, fstride, pitch)
+    assert torch.equal(c0, c1) and int(c0[0]) == golden_tiny.fx["kpts"].shape[0]
+    for i in range(b):
+        k = int(c0[i])
+        assert torch.equal(r0[i, :k], r1[i, :k]) and torch.equal(x0[i, :k], x1[i, :k])
+    assert np.array_equal(r0[0, :int(c0[0]), :2].numpy(), golden_tiny.fx["kpts"])
