@@ -381,7 +381,7 @@ extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches
                                    int32_t* d_corners, float* d_xy, float* d_heat, void* stream) {
     if (!rf || !d_patches || !d_ws) return DCX_E_ARG;
     if (d_xy != nullptr && d_table == nullptr) return DCX_E_ARG;
-    if (max_patches <= 0 || max_patches > 65535) return DCX_E_SHAPE;
+    if (max_patches <= 0 || max_patches > (1 << 22)) return DCX_E_SHAPE;
     const RefWs L = ref_layout(max_patches);
     if (ws_bytes < L.total) return DCX_E_WS;
     hipStream_t s = (hipStream_t)stream;
@@ -459,7 +459,7 @@ extern "C" int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf, c
                                void* stream) {
     if (!det || !d_frames_u8 || !d_ws || !d_counts || !d_rows) return DCX_E_ARG;
     if (rf != nullptr && d_xy == nullptr) return DCX_E_ARG;
-    if (kmax <= 0 || (long)batch * kmax > 65535) return DCX_E_SHAPE;
+    if (kmax <= 0 || (long)batch * kmax > (1 << 22)) return DCX_E_SHAPE;
     const PipeWs L = pipe_layout(det, rf, batch, height, width, kmax);
     if (ws_bytes < L.total) return DCX_E_WS;
     hipStream_t s = (hipStream_t)stream;

@@ -24,10 +24,11 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ 
                                                           const float* __restrict__ alpha,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ out, int ho, int wo,
-                                                          const int* __restrict__ n_limit) {
+                                                          const int* __restrict__ n_limit, int n_images) {
     __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
-    const int n = blockIdx.y;
-    if (n_limit != nullptr && n >= *n_limit) return;
+    int n_end = n_images;
+    if (n_limit != nullptr) n_end = min(n_end, *n_limit);
+    if ((int)blockIdx.y >= n_end) return;
     for (int i = threadIdx.x; i < 9 * 64; i += 256) sw[i] = w9x64[i];
     if (threadIdx.x < 64) {
         sw[576 + threadIdx.x] = bias[threadIdx.x];
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ 
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ho * wo) return;
     const int oy = p / wo, ox = p - oy * wo;
+    for (int n = blockIdx.y; n < n_end; n += gridDim.y) {     // gridDim.y is capped at 65535 images
     const TIn* img = in + (size_t)n * image_stride;
     float x[9];
 #pragma unroll
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ 
         y.w = fmaxf(fmaf(acc.w + bi.w, al.w, be.w), 0.f);
         out4[((size_t)n * 16 + cq) * (size_t)(ho * wo) + p] = y;
     }
+    }
 }
 
 template <typename TIn>
@@ -79,10 +82,10 @@ static int launch_conv1(const TIn* in, long image_stride, int pitch, int n, int 
                         float* out, const int* n_limit, hipStream_t s) {
     if (!in || !w9x64 || !bias || !alpha || !beta || !out) return DCX_E_ARG;
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
-    if (ho <= 0 || wo <= 0 || n <= 0 || n > 65535) return DCX_E_SHAPE;
-    dim3 grid((unsigned)((ho * wo + 255) / 256), (unsigned)n);
+    if (ho <= 0 || wo <= 0 || n <= 0) return DCX_E_SHAPE;
+    dim3 grid((unsigned)((ho * wo + 255) / 256), (unsigned)(n < 65535 ? n : 65535));
     hipLaunchKernelGGL((dcx_conv1_kernel<TIn>), grid, dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
-                       w9x64, bias, alpha, beta, out, ho, wo, n_limit);
+                       w9x64, bias, alpha, beta, out, ho, wo, n_limit, n);
     return (int)hipGetLastError();
 }
 

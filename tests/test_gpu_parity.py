@@ -576,3 +576,12 @@ def test_pitched_frame_buffer_through_c_abi(dev, golden_tiny):
         k = int(c0[i])
         assert torch.equal(r0[i, :k], r1[i, :k]) and torch.equal(x0[i, :k], x1[i, :k])
     assert np.array_equal(r0[0, :int(c0[0]), :2].numpy(), golden_tiny.fx["kpts"])
+
+
+def test_large_patch_capacity(dev, golden_tiny):
+    """batch * kmax beyond 65,535 patch slots (gridDim.y limit of the first-layer kernel) still works."""
+    from deepcharuco_amd.inference import infer_batch
+    dc, rn = _models(golden_tiny, dev)
+    frames = np.repeat(golden_tiny.frame[None], 70, axis=0)
+    res = infer_batch(frames, 16, dc, rn, kmax=1024)          # 71,680 slots
+    assert all(np.array_equal(r, golden_tiny.fx["final_rn"]) for r in res)
