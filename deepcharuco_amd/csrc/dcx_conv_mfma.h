@@ -80,11 +80,6 @@ struct DcxConvCfg {
 
 __device__ __forceinline__ float4 dcx_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// lane exchange inside a quad of lanes (DPP quad_perm): 0xB1 = [1,0,3,2] (xor 1), 0x4E = [2,3,0,1] (xor 2)
-template <int CTRL>
-__device__ __forceinline__ float dcx_quad_perm(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
-}
 // One v_max_f32.  fmaxf() makes hipcc emit an extra canonicalising v_max per operand (sNaN quieting);
 // activations here are finite, and the epilogue runs with the matrix pipe idle, so every VALU counts.
 __device__ __forceinline__ float dcx_vmax(float x, float y) {
@@ -344,23 +339,23 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         const bool n_interior = tile_interior(nxt);
         bool p_in[PPS];
         unsigned poff[PPS];
-        auto off_part = [&](int part, int for_step) {
+        auto off_part = [&](int part, int for_step) {     // part 0: in-bounds predicate, part 1: select the offset
             if (for_step >= C::LOAD_STEPS) return;
 #pragma unroll
             for (int k = 0; k < PPS; ++k) {
                 const int pi = for_step * PPS + k;
                 if (pi >= ITER) continue;
                 if (n_interior) {                     // uniform: no VALU at all
-                    if (part == 3) poff[k] = p_rel[pi];
+                    if (part == 1) poff[k] = p_rel[pi];
                 } else if (part == 0) {
                     const int ly = nsy0 + p_hy[pi], lx = nsx0 + p_hx[pi];
                     p_in[k] = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
-                } else if (part == 3) {
+                } else {
                     poff[k] = p_in[k] ? p_rel[pi] : 0x80000000u;   // out of range -> the buffer load returns zeros
                 }
             }
         };
-        off_part(0, 0); off_part(1, 0); off_part(2, 0); off_part(3, 0);   // step 0's piece (exposed once per unit)
+        off_part(0, 0); off_part(1, 0);   // step 0's piece (exposed once per unit)
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             int pair = 0;
@@ -413,15 +408,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
             if (pair < C::NPAIR) mfma_pair();
-            // mini-slots E0..E3: 2-4 VALU each of the NEXT step's staging address, one per MFMA pair
+            // slots E0, E1: the NEXT step's staging address (border tiles only: predicate, then select)
 #pragma unroll
-            for (int part = 0; part < 4; ++part) {
+            for (int part = 0; part < 2; ++part) {
                 off_part(part, step + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (pair < C::NPAIR) mfma_pair();
             }
 #pragma unroll
-            for (int rest = 8; rest < C::NPAIR; ++rest) mfma_pair();
+            for (int rest = 6; rest < C::NPAIR; ++rest) mfma_pair();
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { a_c0[mt] = aq[STEPS][mt]; a_c1[mt] = aq[STEPS + 1][mt]; }

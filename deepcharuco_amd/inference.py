@@ -74,10 +74,12 @@ def infer_batch_device(frames: torch.Tensor, dust_bin_ids: int, deepc, refinenet
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Enqueue detect+refine for a batch of GPU-resident gray frames; no host synchronisation.
 
-    frames: (B,H,W) uint8 on the GPU.  Returns the packed result tensor (int32, on the GPU):
-    ``out[b, 0, 0]`` = number of firing cells of frame b, ``out[b, 1+k]`` = (x, y, id, cell) of the
-    k-th corner in raster order followed by (x_refined, y_refined) as float32 bit patterns:
-    shape (B, 1 + kmax, 6).  Rows k >= count are unspecified.  Use ``unpack_results`` on the host.
+    frames: (B,H,W) uint8 on the GPU.  Returns the packed result tensor (flat int32, on the GPU), one
+    allocation so that one D2H (or one all-gather) moves everything:
+        [0, B)                      counts[b]      firing cells of frame b (may exceed kmax)
+        [B, B + 4*B*kmax)           rows[b][k]     (x, y, id, cell) of the k-th corner, raster order
+        [B + 4*B*kmax, B + 6*B*kmax) xy[b][k]      refined (x, y) as float32 bit patterns (if refinenet)
+    Entries k >= min(counts[b], kmax) are unspecified.  Use ``unpack_results`` on the host.
     """
     det, ref = _unwrap(deepc, refinenet)
     dev = det.device
