@@ -1,0 +1,36 @@
+#!/usr/bin/env bash
+# Regenerates profiles/rNN_* on an MI355X box (run from the repo root through gpurun):
+#   gpurun --timeout 1500 -- 'bash tools/run_profiles.sh 01'
+# then, back in the build container:   bash tools/run_profiles.sh 01 summarize
+# Counter passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with
+# tracing other than the implicit kernel dispatch records), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
+set -u
+R=${1:-01}
+MODE=${2:-collect}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out
+if [ "$MODE" = collect ]; then
+    mkdir -p "$OUT"; export TMPDIR=/tmp
+    (cd "$ROOT" && timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.log" 2>&1; echo "bench exit $?" >> "$OUT/bench.log")
+    cd /tmp
+    rm -rf "$OUT"/prof_r${R}*
+    B="python $ROOT/bench.py --no-cpu-baseline"
+    timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}" -o r${R} -- $B --steps 10 --warmup 3 > "$OUT/rocprof.log" 2>&1
+    timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_fetch" -o fetch -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_fetch.log" 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/prof_r${R}_write" -o write -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_write.log" 2>&1
+    timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
+        -d "$OUT/prof_r${R}_sq" -o sq -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_sq.log" 2>&1
+    timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE \
+        -d "$OUT/prof_r${R}_lds" -o lds -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_lds.log" 2>&1
+    tail -1 "$OUT/bench.log"
+else
+    cd "$ROOT"
+    python tools/make_pmc_traffic.py gpurun_out/prof_r${R}_fetch/fetch_results.db gpurun_out/prof_r${R}_write/write_results.db > profiles/pmc_traffic.json
+    python tools/rocprof_summary.py gpurun_out/prof_r${R}/r${R}_results.db | cut -c1-220 > profiles/r${R}_kernel_stats.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_fetch/fetch_results.db dcx_ > profiles/r${R}_pmc_fetch_size.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_write/write_results.db dcx_ > profiles/r${R}_pmc_write_size.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_sq/sq_results.db dcx_conv_mfma > profiles/r${R}_pmc_sq.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_lds/lds_results.db dcx_conv_mfma > profiles/r${R}_pmc_lds_valu.txt
+    grep '^{' gpurun_out/bench.log > profiles/r${R}_bench_n1.json
+    ls -la profiles/
+fi
