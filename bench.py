@@ -63,29 +63,53 @@ def pmc_traffic(kernel_name):
         return None
 
 
-def cpu_baseline(sd_dc, sd_rn, frames_u8, budget_s=18.0):
-    """The oracle (CPU restatement of the reference, verified identical to it) timed on this host's
-    cores with the reference's own protocol (src/benchmark.py:37-53: bs=1 loop after warm-up).
-    oneDNN at bs=1 does not scale to every core of a big host, so a few thread counts are tried
-    within the time budget and the fastest is reported together with the threads it used."""
+def cpu_baseline(sd_dc, sd_rn, frames_u8, budget_s=24.0):
+    """The oracle (CPU restatement of the reference, verified identical to it) timed on this host's cores, on a
+    bounded sample of the same workload, two ways:
+      * the reference's own protocol (src/benchmark.py:37-53): bs=1 infer_image loop after warm-up;
+      * one batched pass per thread count (detector on all B frames at once, RefineNet on all patches at once),
+        which is what a CPU user after throughput would run.
+    oneDNN does not scale to every core of a big host at these sizes, so a few thread counts are tried inside the time
+    budget; `value` is the best rate found, `cores` the threads that produced it."""
     from oracle import deepcharuco_oracle as O
     t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
     ncpu = os.cpu_count() or 1
-    tried = {}
-    cands = sorted({min(ncpu, c) for c in (8, 16, 32, ncpu)})
+    cands = sorted({min(ncpu, c) for c in (8, 16, 32, 64)})   # more threads only get slower at these sizes (tried 256)
+    B = len(frames_u8)
+    x_all = torch.from_numpy(np.stack([O.pre_bgr_image(f) for f in frames_u8]))          # (B,1,H,W)
+
+    def batched():
+        loc, ids = O.detector_forward(t_dc, x_all)
+        patches, kp = [], []
+        for b in range(B):
+            k, _ = O.pred_to_keypoints(loc[b:b + 1], ids[b:b + 1], 16)
+            if k.shape[0]:
+                patches.append(O.extract_patches(x_all[b], k)); kp.append(k)
+        if patches:
+            O.refinenet_infer_patches(t_rn, torch.cat(patches), torch.cat(kp))
+
+    single, batch = {}, {}
     for c in cands:
         torch.set_num_threads(c)
         O.infer_image(None, 16, t_dc, t_rn, gray=frames_u8[0])   # warm-up
         n, t0 = 0, time.time()
-        while (time.time() - t0) < budget_s / len(cands) and n < 64:
-            O.infer_image(None, 16, t_dc, t_rn, gray=frames_u8[n % len(frames_u8)])
+        while (time.time() - t0) < 0.5 * budget_s / len(cands) and n < 64:
+            O.infer_image(None, 16, t_dc, t_rn, gray=frames_u8[n % B])
             n += 1
-        tried[c] = (n / (time.time() - t0), n)
-    best = max(tried, key=lambda c: tried[c][0])
-    return {"value": round(tried[best][0], 3), "unit": "frames/s", "cores": int(best), "kind": "port",
-            "sample": f"{tried[best][1]} frames 320x240, bs=1 loop through oracle.infer_image (torch-CPU fp32 restatement "
-                      f"of the reference, same weights/frames as the GPU run); threads tried "
-                      + ", ".join(f"{c}: {v[0]:.2f} fps" for c, v in tried.items()) + f"; host has {ncpu} logical CPUs"}
+        single[c] = (n / (time.time() - t0), n)
+        if c in (16, 32):
+            t0 = time.time()
+            batched()
+            batch[c] = B / (time.time() - t0)
+    best_s = max(single, key=lambda c: single[c][0])
+    best_b = max(batch, key=lambda c: batch[c]) if batch else None
+    use_batch = best_b is not None and batch[best_b] > single[best_s][0]
+    return {"value": round(batch[best_b] if use_batch else single[best_s][0], 3), "unit": "frames/s",
+            "cores": int(best_b if use_batch else best_s), "kind": "port",
+            "sample": ("best of two CPU protocols on the same weights/frames as the GPU run (torch-CPU fp32 restatement of the "
+                       "reference = oracle): bs=1 infer_image loop [" + ", ".join(f"{c} thr: {v[0]:.1f} fps" for c, v in single.items())
+                       + f"] ({single[best_s][1]} frames at the best setting); one batched pass of {B} frames 320x240 ["
+                       + ", ".join(f"{c} thr: {v:.1f} fps" for c, v in batch.items()) + f"]; host has {ncpu} logical CPUs")}
 
 
 def main():
