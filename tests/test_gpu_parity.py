@@ -585,3 +585,19 @@ def test_large_patch_capacity(dev, golden_tiny):
     frames = np.repeat(golden_tiny.frame[None], 70, axis=0)
     res = infer_batch(frames, 16, dc, rn, kmax=1024)          # 71,680 slots
     assert all(np.array_equal(r, golden_tiny.fx["final_rn"]) for r in res)
+
+
+def test_reference_demo_resolution_2560x1920(dev):
+    """The reference's demo runs at 8x (inference.py:111-113: input_size = (320*8, 240*8)): one 2560x1920 frame,
+    76,800 cells, against the oracle (also exercises the 32-bit offset headroom of the kernels)."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frame = W.synthetic_frames("board", 31337, 1, 1920, 2560)
+    sd_dc = _calibrated(808, frame, target_per_frame=40)
+    sd_rn = W.synthetic_state_dict("refinenet", 809)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    got = infer_batch(frame, 16, dc, rn, kmax=128)[0]
+    exp = O.infer_image(None, 16, O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn), gray=frame[0])
+    assert exp.shape[0] >= 30
+    assert got.shape == exp.shape and np.array_equal(got, exp)
