@@ -170,3 +170,13 @@ def test_c_restatement_agrees_with_torch_fp32():
             ref = F.max_pool2d(ref, 2, 2)
         assert got.shape == tuple(ref.shape)
         assert np.abs(got - ref.numpy()).max() <= 2e-5
+
+
+def test_missing_native_library_fails_loudly(monkeypatch, tmp_path):
+    """No fallback: without libdeepcharuco_amd.so every entry into the library raises (nothing is computed on the
+    CPU or through stock PyTorch operators instead)."""
+    from deepcharuco_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libdeepcharuco_amd.so"))
+    with pytest.raises(RuntimeError, match="no CPU / stock-PyTorch fallback"):
+        _lib.lib()
