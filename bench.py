@@ -251,6 +251,8 @@ def main():
         full = fetch_profile(total_patches)
         L.dcx_profile_enable(0)
         kname = lambda k: L.dcx_profile_kernel_name(k).decode()
+        if dom_id not in timed:                 # e.g. --warmup 0: everything was bracketed, pick the dominant kernel now
+            dom_id = max(timed.items(), key=lambda kv: kv[1][1])[0]
         flop, msum, launches, clk = timed[dom_id]
         achieved = flop / (msum * 1e-3) / 1e12
         conv_ms = sum(a[1] for a in full.values())
