@@ -125,6 +125,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     constexpr int WN = C::WN, MT = C::MT, NT = C::NT, TW = C::TW, KS = C::KS;
     constexpr int HW = C::HW, HALO = C::HALO, STEPS = C::STEPS, ITER = C::ITER, PPS = C::PPS;
     constexpr int LDSF = C::LDS_FLOAT4, CQC = C::CQC;
+    constexpr bool P4 = C::POOL && MT == 1 && NT == 4;   // 2x2 pooling window held inside one lane
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -163,9 +164,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     bool qok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int q = (wn * NT + nt) * 32 + l31;
+        int q = (wn * NT + nt) * 32 + l31;
         int qy, qx;
-        if (C::POOL) {   // lanes 4i..4i+3 hold one 2x2 pooling window
+        if (P4) {        // the lane's four n-tiles hold the four pixels of one 2x2 pooling window
+            const int pq = wn * 32 + l31;
+            const int py = pq / (TW / 2), px = pq - py * (TW / 2);
+            qy = 2 * py + (nt >> 1);
+            qx = 2 * px + (nt & 1);
+            q = pq * 4;
+        } else if (C::POOL) {   // lanes 4i..4i+3 hold one 2x2 pooling window
             const int pq = q >> 2, sub = q & 3;
             const int py = pq / (TW / 2), px = pq - py * (TW / 2);
             qy = 2 * py + (sub >> 1);
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
             for (int nt = 0; nt < NT; ++nt) {
                 int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
                 bool ok = qok[nt] && sy < a.ho && sx < a.wo;
-                if (C::POOL) { ok = ok && (l31 & 3) == 0; sy >>= 1; sx >>= 1; }
+                if (C::POOL) { ok = ok && (P4 || (l31 & 3) == 0); sy >>= 1; sx >>= 1; }
                 pix_ok[nt] = ok;
                 lane_off[nt] = ((unsigned)half * plane + (unsigned)(sy * ws + sx)) * 16u;
             }
@@ -458,6 +465,23 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cq = (cur.ct * C::COUT_TILE >> 2) + (wm * MT + mt) * 8 + 2 * g + half;  // output channel quad
+                    if (P4) {   // BN on the four window pixels, in-lane max, one ReLU, one store
+                        float4 m;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1],
+                                                   acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+                            v = dcx_fma4(v, al[g], be[g]);
+                            if (nt == 0) m = v;
+                            else { m.x = dcx_vmax(m.x, v.x); m.y = dcx_vmax(m.y, v.y);
+                                   m.z = dcx_vmax(m.z, v.z); m.w = dcx_vmax(m.w, v.w); }
+                        }
+                        m.x = dcx_vmax(m.x, 0.f); m.y = dcx_vmax(m.y, 0.f);
+                        m.z = dcx_vmax(m.z, 0.f); m.w = dcx_vmax(m.w, 0.f);
+                        if (pix_ok[0] && cq < a.cout_quads)
+                            *reinterpret_cast<float4*>(obase + (size_t)((unsigned)(mt * 8 + 2 * g) * plane * 16u) + lane_off[0]) = m;
+                        continue;
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1],

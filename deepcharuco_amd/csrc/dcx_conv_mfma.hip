@@ -8,12 +8,13 @@ namespace {
 
 struct CfgEntry {
     int cout_tile, cap, th, tw, ks, pool, epi, acc_tiles;
+    int inlane;   // pooled layout with the 2x2 window inside one lane (MT=1, NT=4): no cross-lane max
     int (*launch)(DcxConvArgs, hipStream_t);
     const char* name;
 };
 
 #define DCX_CFG(WM, WN, MT, NT, TH, TW, KS, POOL, EPI)                                              \
-    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT,                                           \
+    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT, ((POOL) != 0 && MT == 1 && NT == 4) ? 1 : 0, \
       &dcx_conv_launch_cfg<DcxConvCfg<WM, WN, MT, NT, TH, TW, KS, (POOL) != 0, EPI>>,                 \
       "dcx_conv_mfma_kernel<DcxConvCfg<" #WM "," #WN "," #MT "," #NT "," #TH "," #TW "," #KS "," #POOL "," #EPI ">>" }
 
@@ -44,7 +45,16 @@ const CfgEntry kCfgs[] = {
     // RefineNet head: 3x3 + BN + ReLU + 1x1 -> 1 channel + tile arg-max
     DCX_CFG(1, 4, 2, 4, 16, 32, 3, 0, DCX_EPI_HEAT),
     DCX_CFG(1, 4, 2, 2, 8, 32, 3, 0, DCX_EPI_HEAT),
+    // pooled, in-lane window (2x2 waves, 32 couts x 128 px per wave): measured +1% on conv1b/conv2b at 8x32,
+    // no gain at 12x20 / 16x16 (A/B in profiles/README.md), so only the 8x32 tile has this variant
+    DCX_CFG(2, 2, 1, 4, 8, 32, 3, 1, DCX_EPI_BNRELU),
 };
+
+int dcx_inlane_pool_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_INLANE_POOL"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v;
+}
 
 int dcx_big_tiles_disabled() {
     static int v = -1;
@@ -65,13 +75,14 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
     for (const CfgEntry& c : kCfgs) {
         if (c.ks != ks || c.pool != pool || c.epi != epi) continue;
         if (cout_pad % c.cout_tile != 0) continue;
+        if (c.inlane && !dcx_inlane_pool_enabled()) continue;
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
         if (c.cap > 256 && (dcx_big_tiles_disabled() || (double)ho * wo / ((double)tiles * c.cap) < 0.999)) continue;
         const double items = (double)n * (cout_pad / c.cout_tile) * tiles;
         const int units = cin / DCX_CCH;
         const int steps = ks * ks * (DCX_CCH / 8);
         const double item_cost = (double)units * steps * (4 * c.acc_tiles) * 64.0 + units * 520.0
-                               + c.acc_tiles * 16 * (pool ? 60.0 : 40.0);
+                               + c.acc_tiles * 16 * (c.inlane ? 35.0 : (pool ? 60.0 : 40.0));
         const double rounds = (double)(((long)items + n_cu - 1) / n_cu);
         double cost = rounds * item_cost;
         if (c.cout_tile == 64 && c.cap == 256) cost *= 0.999;   // deterministic tie-break towards the A layout

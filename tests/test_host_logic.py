@@ -129,7 +129,7 @@ def test_tile_cost_model_choices():
     from deepcharuco_amd import _lib
     L = _lib.lib()
     name = lambda *a: L.dcx_conv_pick_name(*a).decode()
-    A_POOL = "dcx_conv_mfma_kernel<DcxConvCfg<1,4,2,2,8,32,3,1,DCX_EPI_BNRELU>>"
+    A_POOL = "dcx_conv_mfma_kernel<DcxConvCfg<2,2,1,4,8,32,3,1,DCX_EPI_BNRELU>>"   # in-lane pooling window
     assert name(32, 64, 240, 320, 64, 3, 1, 0) == A_POOL                       # conv1b, bs=32
     assert name(128, 64, 480, 640, 64, 3, 1, 0) == A_POOL                      # conv1b, cfg3
     assert "<1,4,2,2,8,32,3,0,DCX_EPI_BNRELU>" in name(32, 64, 120, 160, 64, 3, 0, 0)    # conv2a
