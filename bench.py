@@ -257,7 +257,17 @@ def main():
         achieved = flop / (msum * 1e-3) / 1e12
         conv_ms = sum(a[1] for a in full.values())
         conv_flop = sum(a[0] for a in full.values())
+        # The 1-D Winograd F(2,3) kernels execute 2/3 of a layer's ALGORITHMIC multiply-adds on the matrix cores (4
+        # products per 2 outputs and kernel row instead of 6), so `achieved` (algorithmic FLOP / time, the figure this
+        # contract asks for) can exceed the fp32-MFMA peak; `executed_*` is what the matrix pipe really ran.
+        wino = "wino" in kname(dom_id)
+        exec_scale = 2.0 / 3.0 if wino else 1.0
+        conv_exec = sum(a[0] * (2.0 / 3.0 if "wino" in kname(k) else 1.0) for k, a in full.items())
         roofline = {"bound": "mfma", "kernel": kname(dom_id), "launches": launches,
+                    "algorithm": ("winograd F(2,3) along x: 2/3 of the algorithmic MACs are executed" if wino
+                                  else "direct implicit GEMM"),
+                    "executed_achieved": round(achieved * exec_scale, 2),
+                    "executed_frac": round(achieved * exec_scale / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(msum / launches, 4),
                     "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3),
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -266,6 +276,7 @@ def main():
                     "all_conv_kernels": {"achieved": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(conv_ms / extra_steps, 3),
                                          "frac": round(conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                         "executed_frac": round(conv_exec / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                          "source": f"{extra_steps} fully bracketed steps after the timed region"},
                     "per_kernel": {kname(k): {"ms_per_step": round(v[1] / extra_steps, 4),
                                               "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,

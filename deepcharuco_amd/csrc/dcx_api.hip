@@ -26,6 +26,22 @@ std::vector<float> pack_conv(const float* w, int cout, int cin, int ks, int cout
     return out;
 }
 
+// 3x3 OIHW -> 1-D Winograd F(2,3) along x: [ky*4 + p][cin/4][cout_pad][4], u = G g per kernel row (dcx_conv_wino.h).
+// fp32, in this order (restated by oracle/conv_exact.c): u1 = ((g0+g1)+g2)*0.5f, u2 = ((g0-g1)+g2)*0.5f.
+std::vector<float> pack_conv_wino(const float* w, int cout, int cin, int cout_pad) {
+    const int cq = cin / 4;
+    std::vector<float> out((size_t)12 * cq * cout_pad * 4, 0.0f);
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i)
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* g = w + ((size_t)o * cin + i) * 9 + ky * 3;
+                const float u[4] = {g[0], ((g[0] + g[1]) + g[2]) * 0.5f, ((g[0] - g[1]) + g[2]) * 0.5f, g[2]};
+                for (int p = 0; p < 4; ++p)
+                    out[(((size_t)(ky * 4 + p) * cq + (i >> 2)) * cout_pad + o) * 4 + (i & 3)] = u[p];
+            }
+    return out;
+}
+
 // eval-mode BatchNorm2d as ATen's CPU inference path evaluates it: y = x * alpha + beta with
 // alpha = gamma * (1 / sqrt(var + eps)), beta = bn_bias - mean * alpha   (fp32 throughout).
 void fold_bn(const float* gamma, const float* bbeta, const float* mean, const float* var, int c, int c_pad,
@@ -48,6 +64,7 @@ std::vector<float> pad_vec(const float* v, int c, int c_pad) {
 
 struct DevLayer {       // one MFMA convolution's parameters on the device
     float* w = nullptr;
+    float* w_wino = nullptr;   // 3x3 + BN layers only
     float* bias = nullptr;
     float* alpha = nullptr;
     float* beta = nullptr;
@@ -62,6 +79,7 @@ int upload(const std::vector<float>& h, float** d) {
 
 void free_layer(DevLayer& l) {
     if (l.w) (void)hipFree(l.w);
+    if (l.w_wino) (void)hipFree(l.w_wino);
     if (l.bias) (void)hipFree(l.bias);
     if (l.alpha) (void)hipFree(l.alpha);
     if (l.beta) (void)hipFree(l.beta);
@@ -87,6 +105,7 @@ int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out) {
         for (int i = 0; i < cout; ++i) be[i] = fmaf(h.b[i], al[i], be[i]);
         rc = upload(al, &l.alpha);
         if (rc == 0) rc = upload(be, &l.beta);
+        if (rc == 0 && ks == 3) rc = upload(pack_conv_wino(h.w, cout, cin, l.cout_pad), &l.w_wino);
     }
     if (rc != 0) { free_layer(l); return rc; }
     *out = l;
@@ -182,7 +201,7 @@ DcxConvArgs conv_args(const DevLayer& l, const float* in, int n, int in_cq_total
                       int ups, int pad, float* out, int out_cq_total, const int* n_limit) {
     DcxConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.w = l.w; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
+    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
     a.n_limit = n_limit;
     a.n = n; a.in_cq_total = in_cq_total; a.in_cq_off = in_cq_off; a.cin = l.cin;
     a.hin = hin; a.win = win; a.ups = ups; a.pad = pad;

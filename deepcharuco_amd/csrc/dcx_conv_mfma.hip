@@ -1,7 +1,9 @@
 // dcx_conv_mfma.hip -- instantiations and tile selection for the MFMA convolution kernel.
 #include "dcx_conv_mfma.h"
+#include "dcx_conv_wino.h"
 
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 namespace {
@@ -9,14 +11,20 @@ namespace {
 struct CfgEntry {
     int cout_tile, cap, th, tw, ks, pool, epi, acc_tiles;
     int inlane;   // pooled layout with the 2x2 window inside one lane (MT=1, NT=4): no cross-lane max
+    int wino;     // 1-D Winograd F(2,3) kernel (dcx_conv_wino.h): 12 instead of 18 k-steps per 16 channels
     int (*launch)(DcxConvArgs, hipStream_t);
     const char* name;
 };
 
 #define DCX_CFG(WM, WN, MT, NT, TH, TW, KS, POOL, EPI)                                              \
-    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT, ((POOL) != 0 && MT == 1 && NT == 4) ? 1 : 0, \
+    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT, ((POOL) != 0 && MT == 1 && NT == 4) ? 1 : 0, 0, \
       &dcx_conv_launch_cfg<DcxConvCfg<WM, WN, MT, NT, TH, TW, KS, (POOL) != 0, EPI>>,                 \
       "dcx_conv_mfma_kernel<DcxConvCfg<" #WM "," #WN "," #MT "," #NT "," #TH "," #TW "," #KS "," #POOL "," #EPI ">>" }
+
+#define DCX_WCFG(WM, WN, TH, TW, POOL)                                                                \
+    { WM * 32, WN * 64, TH, TW, 3, POOL, DCX_EPI_BNRELU, 4, 0, 1,                                          \
+      &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, (POOL) != 0>>,                                  \
+      "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW "," #POOL ">>" }
 
 // Wave layouts:  A = 1x4 waves, 64 couts x 256 px   B = 2x2 waves, 128 couts x 128 px
 //                C = 4x1 waves, 128 couts x 64 px
@@ -48,7 +56,20 @@ const CfgEntry kCfgs[] = {
     // pooled, in-lane window (2x2 waves, 32 couts x 128 px per wave): measured +1% on conv1b/conv2b at 8x32,
     // no gain at 12x20 / 16x16 (A/B in profiles/README.md), so only the 8x32 tile has this variant
     DCX_CFG(2, 2, 1, 4, 8, 32, 3, 1, DCX_EPI_BNRELU),
+    // 1-D Winograd F(2,3): 2x2 waves, 64 couts x 64 output pairs (128 px)
+    DCX_WCFG(2, 2, 4, 32, 0),
+    DCX_WCFG(2, 2, 8, 16, 0),
+    DCX_WCFG(2, 2, 6, 20, 0),
+    DCX_WCFG(2, 2, 4, 32, 1),
+    DCX_WCFG(2, 2, 8, 16, 1),
+    DCX_WCFG(2, 2, 6, 20, 1),
 };
+
+int dcx_wino_enabled() {   // on by default; DCX_WINO=0 keeps every layer on the direct kernels (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_WINO"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v;
+}
 
 int dcx_inlane_pool_enabled() {
     static int v = -1;
@@ -72,17 +93,28 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
     const CfgEntry* best = nullptr;
     double best_cost = 0.0;
     const int n_cu = dcx_device_cu_count();
+    // test hook: DCX_FORCE_CFG=<kernel name> restricts the choice to that instantiation when it can run the layer
+    // (read on every call so that a test can walk through all instantiations); otherwise the cost model decides
+    const char* force = getenv("DCX_FORCE_CFG");
+    if (force != nullptr && force[0] != 0) {
+        for (const CfgEntry& c : kCfgs)
+            if (strcmp(c.name, force) == 0 && c.ks == ks && c.pool == pool && c.epi == epi && cout_pad % c.cout_tile == 0)
+                return &c;
+    }
     for (const CfgEntry& c : kCfgs) {
         if (c.ks != ks || c.pool != pool || c.epi != epi) continue;
         if (cout_pad % c.cout_tile != 0) continue;
         if (c.inlane && !dcx_inlane_pool_enabled()) continue;
+        if (c.wino && !dcx_wino_enabled()) continue;
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
         if (c.cap > 256 && (dcx_big_tiles_disabled() || (double)ho * wo / ((double)tiles * c.cap) < 0.999)) continue;
         const double items = (double)n * (cout_pad / c.cout_tile) * tiles;
         const int units = cin / DCX_CCH;
-        const int steps = ks * ks * (DCX_CCH / 8);
-        const double item_cost = (double)units * steps * (4 * c.acc_tiles) * 64.0 + units * 520.0
-                               + c.acc_tiles * 16 * (c.inlane ? 35.0 : (pool ? 60.0 : 40.0));
+        const int steps = (c.wino ? 3 : ks * ks) * (DCX_CCH / 8);   // Winograd: (ky, 8 channels), 4 positions inside the step
+        // per-unit overhead: barrier + first LDS wait + bookkeeping (520); the Winograd units also pay their input
+        // transform and the scattered staging loads inside the k-loop (measured ~1100 per unit, tools/unit_probe.py)
+        const double item_cost = (double)units * steps * (4 * c.acc_tiles) * 64.0 + units * (c.wino ? 1100.0 : 520.0)
+                               + c.acc_tiles * 16 * (c.wino ? 25.0 : c.inlane ? 35.0 : (pool ? 60.0 : 40.0));
         const double rounds = (double)(((long)items + n_cu - 1) / n_cu);
         double cost = rounds * item_cost;
         if (c.cout_tile == 64 && c.cap == 256) cost *= 0.999;   // deterministic tie-break towards the A layout

@@ -1,0 +1,455 @@
+// dcx_conv_wino.h -- 3x3 convolution + BN + ReLU (+2x2 max-pool) with a 1-D Winograd F(2,3) transform along x,
+// on the gfx950 fp32 matrix cores.  Same layers, same C4 layouts, same persistent software pipeline as
+// dcx_conv_mfma.h (read that file first); what changes is the arithmetic:
+//
+//   for one output row y, one pair of output pixels (x0, x0+1), one kernel row ky and one input channel:
+//       d0..d3 = in[y+ky-pad][x0-pad .. x0-pad+3]
+//       v0 = d0 - d2    v1 = d1 + d2    v2 = d2 - d1    v3 = d1 - d3          (input transform, exact fp32 ops)
+//       u0 = g0         u1 = ((g0+g1)+g2)*0.5f   u2 = ((g0-g1)+g2)*0.5f   u3 = g2   (weights, transformed on the host)
+//       m_p += u_p * v_p                                                      (p = 0..3: FOUR products for TWO outputs
+//                                                                              instead of six -> 1.5x fewer MFMAs)
+//       out[x0] = (m0 + m1) + m2     out[x0+1] = (m1 - m2) - m3               (output transform)
+//
+// GEMM view: four independent GEMMs (one per position p), M = cout, N = output pairs, K = 3 * cin.  A lane owns one
+// output PAIR and keeps the four partial sums m_p in four accumulators, so the output transform, BN, ReLU and the
+// horizontal half of the 2x2 max-pool are in-lane.  The transformed input tile lives in LDS as
+// sV[buf][p][cq][row][pair] float4: the input transform is applied while staging (4 buffer loads, 8 v_pk_add_f32,
+// 4 ds_write_b128 per piece), the k-loop itself is the same VALU-free MFMA stream as in the direct kernel, with
+// "tap" = (ky, p): 12 weight planes instead of 9.
+//
+// Summation order (restated bit-exactly by oracle/conv_exact.c: dcx_conv_wino_exact):
+//   m_p = 0;  for chunk c (16 cin) / ky / s in 0..1 / j in 0..3:
+//                 m_p = fmaf(u_p[8s+j], v_p[8s+j], m_p);  m_p = fmaf(u_p[8s+4+j], v_p[8s+4+j], m_p);
+//   then the output transform above, y = fmaf(out, alpha, beta2), ReLU, max-pool.
+// F(2,3) in one dimension only: error growth is ~2x that of the direct sum (no large transform constants), far
+// inside the 1e-4 logit margin of the parity policy (tests/test_gpu_parity.py).
+#pragma once
+#include "dcx_conv_mfma.h"
+
+// one v_pk_add_f32 (hipcc scalarises float2 +/- into two v_add_f32; every VALU instruction in the k-loop costs matrix time)
+__device__ __forceinline__ dcx_f32x2 dcx_pk_add(dcx_f32x2 x, dcx_f32x2 y) {
+    dcx_f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ dcx_f32x2 dcx_pk_sub(dcx_f32x2 x, dcx_f32x2 y) {
+    dcx_f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+template <int WM_, int WN_, int TH_, int TW_, bool POOL_>
+struct DcxWinoCfg {
+    static constexpr int WM = WM_, WN = WN_, TH = TH_, TW = TW_;
+    static constexpr bool POOL = POOL_;
+    static constexpr int NTHREADS = WM * WN * 64;
+    static constexpr int COUT_TILE = WM * 32;
+    static constexpr int PW = TW / 2;                  // output pairs per tile row
+    static constexpr int CAP = WN * 32;                // output pairs a workgroup can hold
+    static constexpr int TILE_PAIRS = TH * PW;
+    static constexpr int HH = TH + 2;                  // input rows of the tile
+    static constexpr int PLANE = HH * PW;              // float4 per (position, channel quad)
+    static constexpr int CQC = DCX_CCH / 4;
+    static constexpr int PIECES = CQC * PLANE;         // staging work items per unit: (cq, row, pair)
+    static constexpr int ITER = (PIECES + NTHREADS - 1) / NTHREADS;
+    static constexpr int PSTRIDE = ITER * NTHREADS;    // float4 between position planes: padded so that every thread
+                                                       // writes every piece slot (no divergent branch in the k-loop)
+    static constexpr int LDS_FLOAT4 = 4 * PSTRIDE;     // one buffer: 4 positions
+    static constexpr size_t LDS_BYTES = (size_t)2 * LDS_FLOAT4 * 16;
+    static constexpr int STEPS = 3 * (DCX_CCH / 8);    // k-steps per unit: (ky, 8-channel group)
+#ifndef DCX_WINO_DA
+#define DCX_WINO_DA 2
+#endif
+    static constexpr int DA = DCX_WINO_DA;             // weights are requested DA k-steps ahead
+#ifndef DCX_WINO_DP
+#define DCX_WINO_DP 3
+#endif
+    static constexpr int DP = DCX_WINO_DP;             // a staging piece is transformed + written DP k-steps after its loads
+    static constexpr int LOAD_STEPS = STEPS - DP;
+    static constexpr int PPS = (ITER + LOAD_STEPS - 1) / LOAD_STEPS;
+    static constexpr int NPAIR = 8;                    // 16 MFMAs per k-step: 4 registers j x 4 positions p
+    static constexpr int OCC = 2;
+    static_assert(TW % 2 == 0, "tile width must be even");
+    static_assert(TILE_PAIRS <= CAP, "tile does not fit the wave layout");
+    static_assert(!POOL || (TH % 2 == 0 && TILE_PAIRS <= WN * 32), "pooled tiles must have an even height");
+    static_assert(LDS_BYTES * 2 <= 150 * 1024, "LDS tile too large for two workgroups per CU");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(const DcxConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 sB[];
+    constexpr int WN = C::WN, PW = C::PW, PLANE = C::PLANE, PIECES = C::PIECES, PSTRIDE = C::PSTRIDE;
+    constexpr int STEPS = C::STEPS, ITER = C::ITER, PPS = C::PPS, LDSF = C::LDS_FLOAT4, CQC = C::CQC;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- work list (same walk as the direct kernel) ------------------------------------------------
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int n_ct = a.cout_pad / C::COUT_TILE;
+    int n_eff = a.n;
+    if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
+    const int total = n_eff * n_ct * tiles;
+    int w = blockIdx.x;
+    if (w >= total) return;
+    if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+        a.clk_probe[0] = __builtin_amdgcn_s_memtime();
+        a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    const int gstride = gridDim.x;
+    const int nch = a.cin / DCX_CCH;
+    auto decode = [&](int wi) {
+        DcxItem it;
+        it.tx = wi % a.tiles_x; wi /= a.tiles_x;
+        it.ty = wi % a.tiles_y; wi /= a.tiles_y;
+        it.ct = wi % n_ct;
+        it.n = wi / n_ct;
+        return it;
+    };
+    const int hl = a.hin << a.ups, wl = a.win << a.ups;
+
+    // ---- the lane's output pair (tile-relative) ---------------------------------------------------
+    int qy, qxp;
+    bool qok;
+    if (C::POOL) {   // lanes i and i+16 hold vertically adjacent pairs: a 2x2 pooling window = one lane pair
+        const int pq = wn * 16 + (l31 & 15);
+        const int py = pq / PW, px = pq - py * PW;
+        qy = 2 * py + (l31 >> 4);
+        qxp = px;
+        qok = pq < C::TILE_PAIRS / 2;
+    } else {
+        const int q = wn * 32 + l31;
+        qy = q / PW;
+        qxp = q - qy * PW;
+        qok = q < C::TILE_PAIRS;
+    }
+    const int pixb = half * PLANE + (qok ? qy * PW + qxp : 0);
+
+    // ---- operand fetch helpers -------------------------------------------------------------------
+    // weights: [ky*4 + p][cin/4][cout_pad][4]
+    const unsigned w_lane_off = (unsigned)((half * a.cout_pad) + wm * 32 + l31) * 16u;
+    const unsigned w_tap_stride = (unsigned)((a.cin >> 2) * a.cout_pad) * 16u;
+    const unsigned w_s_stride = (unsigned)(2 * a.cout_pad) * 16u;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w_wino), (short)0, (int)(12u * w_tap_stride), 0x00020000);
+    auto unit_wbase = [&](const DcxItem& it, int c) {
+        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u;
+    };
+    auto load_a1 = [&](unsigned wbase, int step, int p) {
+        const int ky = step / (DCX_CCH / 8);
+        const int s = step - ky * (DCX_CCH / 8);
+        const unsigned soff = wbase + (unsigned)(ky * 4 + p) * w_tap_stride + (unsigned)s * w_s_stride;
+        const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane_off, soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto load_a = [&](unsigned wbase, int step, float4 (&dst)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dst[p] = load_a1(wbase, step, p);
+    };
+    auto load_b1 = [&](int buf, int step, int p) {
+        const int ky = step / (DCX_CCH / 8);
+        const int s = step - ky * (DCX_CCH / 8);
+        return sB[buf * LDSF + p * PSTRIDE + (2 * s) * PLANE + pixb + ky * PW];
+    };
+    auto load_b = [&](int buf, int step, float4 (&dst)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dst[p] = load_b1(buf, step, p);
+    };
+    // staging piece pi = (cq, row, pair) #(tid + pi*NTHREADS): four input pixels (tile-relative columns 2*pair + e)
+    int p_hy[ITER], p_hx[ITER];
+    unsigned p_rel[ITER][4];
+#pragma unroll
+    for (int pi = 0; pi < ITER; ++pi) {
+        const int idx = tid + pi * C::NTHREADS;
+        const int cq = idx / PLANE;
+        const int hp = idx - cq * PLANE;
+        p_hy[pi] = hp / PW;
+        p_hx[pi] = 2 * (hp - p_hy[pi] * PW);
+        const int prow = ((p_hy[pi] - a.pad) >> a.ups) + a.pad;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pcol = ((p_hx[pi] + e - a.pad) >> a.ups) + a.pad;
+            p_rel[pi][e] = idx < PIECES ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
+        }
+    }
+    auto unit_rsrc = [&](const DcxItem& it, int c) {
+        const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
+        const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
+                                    + tile_off) * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+    };
+    auto tile_interior = [&](const DcxItem& it) {
+        const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
+        return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + C::TW + 2 <= wl;
+    };
+    auto stage_fetch = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    // input transform of one piece, one position at a time: 2 v_pk_add_f32 + 1 ds_write_b128 (position planes are
+    // PSTRIDE float4 apart; slots past the end of the tile are padding and receive the zeros their loads returned)
+    auto stage_store_p = [&](float4* wbase_lds, int pi, int p, const float4 (&d)[4]) {
+        const float4& x = p == 0 ? d[0] : p == 1 ? d[1] : p == 2 ? d[2] : d[1];
+        const float4& y = p == 0 ? d[2] : p == 1 ? d[2] : p == 2 ? d[1] : d[3];
+        // packed fp32 (two lanes of the float4 per VALU instruction): v_pk_add_f32 with a neg modifier for the differences
+        const dcx_f32x2 xl = {x.x, x.y}, xh = {x.z, x.w}, yl = {y.x, y.y}, yh = {y.z, y.w};
+        const dcx_f32x2 lo = p == 1 ? dcx_pk_add(xl, yl) : dcx_pk_sub(xl, yl), hi = p == 1 ? dcx_pk_add(xh, yh) : dcx_pk_sub(xh, yh);
+        wbase_lds[pi * C::NTHREADS + p * PSTRIDE] = make_float4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto stage_store_at = [&](float4* wbase_lds, int pi, const float4 (&d)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) stage_store_p(wbase_lds, pi, p, d);
+    };
+
+    // ---- epilogue constants in LDS: sP[0] alpha, sP[1] beta2 ---------------------------------------------
+    float4* sP = sB + 2 * LDSF;
+    const int cq_pad = a.cout_pad >> 2;
+    for (int i = tid; i < cq_pad; i += C::NTHREADS) {
+        sP[i] = reinterpret_cast<const float4*>(a.alpha)[i];
+        sP[cq_pad + i] = reinterpret_cast<const float4*>(a.beta)[i];
+    }
+    const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
+
+    dcx_f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    // ---- prologue: first unit staged synchronously ---------------------------------------------
+    DcxItem cur = decode(w);
+    int c = 0;
+    float4 a_c[C::DA][4];          // weights of the first DA k-steps of the unit about to run (carried across units)
+    {
+        const unsigned wb = unit_wbase(cur, 0);
+#pragma unroll
+        for (int d = 0; d < C::DA; ++d) load_a(wb, d, a_c[d]);
+        const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(cur, 0);
+        const int sy0 = cur.ty * C::TH - a.pad, sx0 = cur.tx * C::TW - a.pad;
+#pragma unroll
+        for (int pi = 0; pi < ITER; ++pi) {
+            float4 d[4];
+            const int ly = sy0 + p_hy[pi];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int lx = sx0 + p_hx[pi] + e;
+                const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+                d[e] = stage_fetch(r0, inb ? p_rel[pi][e] : 0x80000000u);
+            }
+            stage_store_at(sB + tid, pi, d);
+        }
+    }
+
+    for (int u = 0;; ++u) {
+        DcxItem nxt = cur;
+        int cn = c + 1;
+        bool has_next = true;
+        if (cn == nch) {
+            if (w + gstride < total) { nxt = decode(w + gstride); cn = 0; }
+            else { has_next = false; cn = c; }
+        }
+        const int buf = u & 1;
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[4 + 3 * u] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[5 + 3 * u] = __builtin_amdgcn_s_memtime();
+
+        const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
+        const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
+        const unsigned wb_cur = unit_wbase(cur, c);
+        const unsigned wb_nxt = unit_wbase(nxt, cn);
+        float4 aq[STEPS + C::DA][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int d = 0; d < C::DA; ++d) aq[d][p] = a_c[d][p];
+        float4 bq[STEPS + 1][4];
+        load_b(buf, 0, bq[0]);
+        float4* lds_w = sB + (buf ^ 1) * LDSF + tid;
+        float4 pv[STEPS][PPS][4];
+        const bool n_interior = tile_interior(nxt);
+        bool p_in[PPS][4];
+        unsigned poff[PPS][4];
+        auto off_part = [&](int part, int for_step) {
+            if (for_step >= C::LOAD_STEPS) return;
+#pragma unroll
+            for (int k = 0; k < PPS; ++k) {
+                const int pi = for_step * PPS + k;
+                if (pi >= ITER) continue;
+                if (n_interior) {
+                    if (part == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) poff[k][e] = p_rel[pi][e];
+                    }
+                } else if (part == 0) {
+                    const int ly = nsy0 + p_hy[pi];
+                    const bool rok = (unsigned)ly < (unsigned)hl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p_in[k][e] = rok && (unsigned)(nsx0 + p_hx[pi] + e) < (unsigned)wl;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) poff[k][e] = p_in[k][e] ? p_rel[pi][e] : 0x80000000u;
+                }
+            }
+        };
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            int pair = 0;
+            auto mfma_pair = [&]() {      // MFMAs 2*pair, 2*pair+1 of the step in (j, p) order
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int f = 2 * pair + e;
+                    const int j = f >> 2, p = f & 3;
+                    const float4 av4 = aq[step][p], bv4 = bq[step][p];
+                    const float av = j == 0 ? av4.x : j == 1 ? av4.y : j == 2 ? av4.z : av4.w;
+                    const float bv = j == 0 ? bv4.x : j == 1 ? bv4.y : j == 2 ? bv4.z : bv4.w;
+                    if (step == 0 && j == 0 && c == 0) {
+                        const dcx_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, zero, 0, 0, 0);
+                    } else {
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
+                    }
+                }
+                ++pair;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // eight slots, one before each MFMA pair (the pair before it covers its issue time); every slot holds at
+            // most one LDS read, one weight load, one staging load and one transform+write, so no slot is long enough
+            // to drain the matrix pipe:
+            //   slots 0..3: B(step+1, p = slot), A(step+DA, p = slot); slots 2, 3 also this step's staging offsets
+            //   slots 4..7: staging load e = slot-4 of this step's piece; transform + write of position p = slot-4 of
+            //               the piece requested DP steps ago
+#pragma unroll
+            for (int slot = 0; slot < 8; ++slot) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (slot < 4) {
+                    if (step + 1 < STEPS) bq[step + 1][slot] = load_b1(buf, step + 1, slot);
+                    if (step + C::DA < STEPS) aq[step + C::DA][slot] = load_a1(wb_cur, step + C::DA, slot);
+                    else aq[step + C::DA][slot] = load_a1(wb_nxt, step + C::DA - STEPS, slot);
+                    if (slot >= 2) off_part(slot - 2, step);   // this step's piece (requested in slots 4..7)
+                } else {
+                    const int e = slot - 4;
+                    if (step < C::LOAD_STEPS) {
+#pragma unroll
+                        for (int k = 0; k < PPS; ++k) {
+                            const int pi = step * PPS + k;
+                            if (pi < ITER) pv[step][k][e] = stage_fetch(rs_n, poff[k][e]);
+                        }
+                    }
+                    if (step >= C::DP) {
+#pragma unroll
+                        for (int k = 0; k < PPS; ++k) {
+                            const int pi = (step - C::DP) * PPS + k;
+                            if (pi < ITER) stage_store_p(lds_w, pi, e, pv[step - C::DP][k]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_pair();
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int d = 0; d < C::DA; ++d) a_c[d][p] = aq[STEPS + d][p];
+
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[6 + 3 * u] = __builtin_amdgcn_s_memtime();
+        if (c == nch - 1) {
+            // ---- epilogue: output transform, BN, ReLU (, pool), store ---------------------------------
+            const int oy0 = cur.ty * C::TH, ox0 = cur.tx * C::TW;
+            const unsigned plane = (unsigned)(hs * ws);
+            const int cq_w0 = (cur.ct * C::COUT_TILE >> 2) + wm * 8;
+            char* obase = reinterpret_cast<char*>(a.out)
+                        + ((size_t)cur.n * a.out_cq_total + a.out_cq_off + cq_w0) * (size_t)plane * 16;
+            const int sy = oy0 + qy, sx = ox0 + 2 * qxp;
+            bool ok0, ok1;
+            unsigned lane_off;
+            if (C::POOL) {
+                ok0 = qok && (l31 < 16) && sy < a.ho && sx < a.wo;
+                ok1 = false;
+                lane_off = ((unsigned)half * plane + (unsigned)((sy >> 1) * ws + (sx >> 1))) * 16u;
+            } else {
+                ok0 = qok && sy < a.ho && sx < a.wo;
+                ok1 = ok0 && sx + 1 < a.wo;
+                lane_off = ((unsigned)half * plane + (unsigned)(sy * ws + sx)) * 16u;
+            }
+            float4 al[4], be[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 8 + 2 * g + half;
+                al[g] = sP[cq];
+                be[g] = sP[cq_pad + cq];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 8 + 2 * g + half;
+                float4 m[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    m[p] = make_float4(acc[p][4 * g + 0], acc[p][4 * g + 1], acc[p][4 * g + 2], acc[p][4 * g + 3]);
+                float4 y0 = make_float4((m[0].x + m[1].x) + m[2].x, (m[0].y + m[1].y) + m[2].y,
+                                        (m[0].z + m[1].z) + m[2].z, (m[0].w + m[1].w) + m[2].w);
+                float4 y1 = make_float4((m[1].x - m[2].x) - m[3].x, (m[1].y - m[2].y) - m[3].y,
+                                        (m[1].z - m[2].z) - m[3].z, (m[1].w - m[2].w) - m[3].w);
+                y0 = dcx_fma4(y0, al[g], be[g]);
+                y1 = dcx_fma4(y1, al[g], be[g]);
+                char* dst = obase + (size_t)((unsigned)(2 * g) * plane * 16u) + lane_off;
+                if (C::POOL) {
+                    float4 v = make_float4(dcx_vmax(y0.x, y1.x), dcx_vmax(y0.y, y1.y), dcx_vmax(y0.z, y1.z), dcx_vmax(y0.w, y1.w));
+                    // vertical neighbour = lane ^ 16 (ds_swizzle: runs on the LDS crossbar, not on the vector ALU)
+                    float4 o;
+                    o.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v.x), 0x401F));
+                    o.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v.y), 0x401F));
+                    o.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v.z), 0x401F));
+                    o.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v.w), 0x401F));
+                    v.x = dcx_vmax(dcx_vmax(v.x, o.x), 0.f); v.y = dcx_vmax(dcx_vmax(v.y, o.y), 0.f);
+                    v.z = dcx_vmax(dcx_vmax(v.z, o.z), 0.f); v.w = dcx_vmax(dcx_vmax(v.w, o.w), 0.f);
+                    if (ok0 && cq < a.cout_quads) *reinterpret_cast<float4*>(dst) = v;
+                } else {
+                    y0.x = dcx_vmax(y0.x, 0.f); y0.y = dcx_vmax(y0.y, 0.f); y0.z = dcx_vmax(y0.z, 0.f); y0.w = dcx_vmax(y0.w, 0.f);
+                    y1.x = dcx_vmax(y1.x, 0.f); y1.y = dcx_vmax(y1.y, 0.f); y1.z = dcx_vmax(y1.z, 0.f); y1.w = dcx_vmax(y1.w, 0.f);
+                    if (cq < a.cout_quads) {
+                        if (ok0) *reinterpret_cast<float4*>(dst) = y0;
+                        if (ok1) *reinterpret_cast<float4*>(dst + 16) = y1;
+                    }
+                }
+            }
+        }
+
+        if (!has_next) {
+            if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+                a.clk_probe[2] = __builtin_amdgcn_s_memtime();
+                a.clk_probe[3] = __builtin_amdgcn_s_memrealtime();
+            }
+            break;
+        }
+        if (cn == 0) w += gstride;
+        cur = nxt;
+        c = cn;
+    }
+}
+
+template <class C>
+static int dcx_conv_wino_launch_cfg(DcxConvArgs a, hipStream_t stream) {
+    a.tiles_x = (a.wo + C::TW - 1) / C::TW;
+    a.tiles_y = (a.ho + C::TH - 1) / C::TH;
+    if (a.w_wino == nullptr || a.alpha == nullptr || a.beta == nullptr) return DCX_E_ARG;
+    if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0) return DCX_E_SHAPE;
+    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
+    if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
+    const int occ_env = dcx_occupancy_override();
+    const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);
+    const long blocks = items < resident ? items : resident;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcx_conv_wino_kernel<C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES + 8192)));
+        attr_set = true;
+    }
+    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 8;   // transformed-tile double buffer + alpha, beta2
+    if (lds > 160 * 1024) return DCX_E_SHAPE;
+    hipLaunchKernelGGL((dcx_conv_wino_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), lds, stream, a);
+    return (int)hipGetLastError();
+}

@@ -69,3 +69,47 @@ void dcx_oracle_conv_exact(const float* x, int n, int cin, int h, int w, const f
                     y[(((size_t)b * cout + co) * ho + oy) * wo + ox] = v;
                 }
 }
+
+/* Same layer through the 1-D Winograd F(2,3) kernel (deepcharuco_amd/csrc/dcx_conv_wino.h), in ITS exact fp32 order:
+ *   per output pair (x0 = 2i, x0+1), kernel row ky, channel:  d_e = in[oy-pad+ky][x0-pad+e], e = 0..3 (0 outside)
+ *     v0 = d0-d2  v1 = d1+d2  v2 = d2-d1  v3 = d1-d3;   u0 = g0  u1 = ((g0+g1)+g2)*0.5f  u2 = ((g0-g1)+g2)*0.5f  u3 = g2
+ *   m_p = 0;  for chunk c0 / ky / s / j / k:  m_p = fmaf(u_p[ci], v_p[ci], m_p),  ci = c0 + 8s + 4k + j
+ *   out[x0] = (m0+m1)+m2,  out[x0+1] = (m1-m2)-m3,  y = max(fmaf(out, alpha, fmaf(bias, alpha, beta)), 0)
+ * 3x3 + BN + ReLU layers only (cin % 16 == 0). */
+void dcx_oracle_conv_wino_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                                const float* alpha, const float* beta, int cout, int pad, float* y) {
+    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
+    const int npair = (wo + 1) / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < n; ++b)
+        for (int co = 0; co < cout; ++co)
+            for (int oy = 0; oy < ho; ++oy)
+                for (int pr = 0; pr < npair; ++pr) {
+                    const int x0 = 2 * pr;
+                    float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int c0 = 0; c0 < cin; c0 += 16)
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int iy = oy - pad + ky;
+                            for (int s = 0; s < 2; ++s)
+                                for (int j = 0; j < 4; ++j)
+                                    for (int k = 0; k < 2; ++k) {
+                                        const int ci = c0 + 8 * s + 4 * k + j;
+                                        float d[4];
+                                        for (int e = 0; e < 4; ++e) {
+                                            const int ix = x0 - pad + e;
+                                            const int inb = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                                            d[e] = inb ? x[(((size_t)b * cin + ci) * h + iy) * w + ix] : 0.0f;
+                                        }
+                                        const float* g = wt + ((size_t)co * cin + ci) * 9 + ky * 3;
+                                        const float u[4] = {g[0], ((g[0] + g[1]) + g[2]) * 0.5f, ((g[0] - g[1]) + g[2]) * 0.5f, g[2]};
+                                        const float v[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+                                        for (int p = 0; p < 4; ++p) m[p] = fmaf(u[p], v[p], m[p]);
+                                    }
+                        }
+                    const float o0 = (m[0] + m[1]) + m[2], o1 = (m[1] - m[2]) - m[3];
+                    const float b2 = fmaf(bias[co], alpha[co], beta[co]);
+                    float* row = y + (((size_t)b * cout + co) * ho + oy) * wo;
+                    row[x0] = fmaxf(fmaf(o0, alpha[co], b2), 0.0f);
+                    if (x0 + 1 < wo) row[x0 + 1] = fmaxf(fmaf(o1, alpha[co], b2), 0.0f);
+                }
+}

@@ -172,6 +172,7 @@ def test_conv_layer_bit_exact_vs_c_restatement(dev, case):
     """The MFMA kernel is an exact sequential fp32 fmaf chain in a documented order; oracle/conv_exact.c
     restates that order in plain C, so the comparison is bit for bit (no tolerance)."""
     from oracle.conv_exact import conv_exact
+    from deepcharuco_amd import _lib
     name, n, cin, cout, h, w, pad, ups, pool, ks, has_bn = case
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 1)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -182,11 +183,62 @@ def test_conv_layer_bit_exact_vs_c_restatement(dev, case):
         bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
               torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
     got = _conv_layer(x.to(dev), wt, b, bn, pad, ups, pool, ks).cpu().numpy()
+    ho, wo = (h << ups) + 2 * pad - (ks - 1), (w << ups) + 2 * pad - (ks - 1)
+    picked = _lib.lib().dcx_conv_pick_name(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1).decode()
     ref = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
-                     pad=pad, ups=bool(ups), pool=bool(pool))
+                     pad=pad, ups=bool(ups), pool=bool(pool), wino="wino" in picked)   # each kernel has its own order
     nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
-    _report(f"conv_layer_bitexact/{name}", dict(mismatching_elements=nbad, max_abs=float(np.abs(got - ref).max())))
+    _report(f"conv_layer_bitexact/{name}", dict(kernel=picked[picked.find("dcx_conv_") + 9:], mismatching_elements=nbad,
+                                                max_abs=float(np.abs(got - ref).max())))
     assert nbad == 0, f"{name}: {nbad} of {got.size} elements differ from the exact-order restatement"
+
+
+def test_every_conv_instantiation_bit_exact(dev, monkeypatch):
+    """The cost model picks the small S tile for test-sized layers, so the parametrised tests above do not reach the
+    big-tile instantiations.  DCX_FORCE_CFG walks EVERY instantiation of the table over every shape variant it can
+    run (padding / valid / up-sampled / pooled / partial tiles) and compares bit for bit with the restatement of
+    that kernel's summation order (direct or 1-D Winograd)."""
+    from oracle.conv_exact import conv_exact
+    from deepcharuco_amd import _lib
+    L = _lib.lib()
+    names = []
+    while True:
+        nm = L.dcx_profile_kernel_name(len(names)).decode()
+        if nm == "?":
+            break
+        names.append(nm)
+    assert len(names) >= 20
+    ran = {}
+    for case in CONV_CASES:
+        name, n, cin, cout, h, w, pad, ups, pool, ks, has_bn = case
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 2)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        bn = None
+        if has_bn:
+            bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+                  torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+        ho, wo = (h << ups) + 2 * pad - (ks - 1), (w << ups) + 2 * pad - (ks - 1)
+        refs = {}
+        for cfg in names:
+            if "HEAT" in cfg:
+                continue      # the fused RefineNet head has its own entry point (covered by the refiner tests)
+            monkeypatch.setenv("DCX_FORCE_CFG", cfg)
+            if L.dcx_conv_pick_name(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1).decode() != cfg:
+                continue      # this instantiation cannot run this layer (kernel size / pooling / cout tile)
+            got = _conv_layer(x.to(dev), wt, b, bn, pad, ups, pool, ks).cpu().numpy()
+            wino = "wino" in cfg
+            if wino not in refs:
+                refs[wino] = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
+                                        pad=pad, ups=bool(ups), pool=bool(pool), wino=wino)
+            nbad = int((got.view(np.uint32) != refs[wino].view(np.uint32)).sum())
+            assert nbad == 0, f"{cfg} on {name}: {nbad} of {got.size} elements differ (max abs {np.abs(got - refs[wino]).max()})"
+            ran[cfg] = ran.get(cfg, 0) + 1
+    monkeypatch.delenv("DCX_FORCE_CFG")
+    _report("conv_instantiations_bitexact", ran)
+    missing = [c for c in names if "HEAT" not in c and c not in ran]
+    assert not missing, f"instantiations never exercised: {missing}"
 
 
 def test_decode_matches_oracle_exactly_with_ties_and_empty(dev):
