@@ -185,7 +185,7 @@ DetWs det_layout(int n_ids, int b, int h, int w) {
 struct RefWs {
     size_t buf0, buf1, pval, pidx, total;
 };
-constexpr int kRefTiles = 16;     // capacity: 64x64 heat-map in 8x32 tiles (8 tiles of 16x32 when the big tile is used)
+constexpr int kRefTiles = 32;     // capacity: 64x64 heat-map in 4x32 tiles (Winograd head; 16 tiles of 8x32 for the direct head)
 RefWs ref_layout(int p) {
     RefWs L;
     size_t off = 0;

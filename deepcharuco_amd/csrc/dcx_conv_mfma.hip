@@ -25,6 +25,10 @@ struct CfgEntry {
     { WM * 32, WN * 64, TH, TW, 3, POOL, DCX_EPI_BNRELU, 4, 0, 1,                                          \
       &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, (POOL) != 0>>,                                  \
       "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW "," #POOL ">>" }
+#define DCX_WCFG_HEAT(WM, WN, TH, TW)                                                                  \
+    { WM * 32, WN * 64, TH, TW, 3, 0, DCX_EPI_HEAT, 4, 0, 1,                                               \
+      &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, false, DCX_EPI_HEAT>>,                          \
+      "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW ",0,DCX_EPI_HEAT>>" }
 
 // Wave layouts:  A = 1x4 waves, 64 couts x 256 px   B = 2x2 waves, 128 couts x 128 px
 //                C = 4x1 waves, 128 couts x 64 px
@@ -63,6 +67,7 @@ const CfgEntry kCfgs[] = {
     DCX_WCFG(2, 2, 4, 32, 1),
     DCX_WCFG(2, 2, 8, 16, 1),
     DCX_WCFG(2, 2, 6, 20, 1),
+    DCX_WCFG_HEAT(2, 2, 4, 32),
 };
 
 int dcx_wino_enabled() {   // on by default; DCX_WINO=0 keeps every layer on the direct kernels (A/B runs)
@@ -231,7 +236,8 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
     if (epi != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
     if (epi != DCX_EPI_RAW && (a.alpha == nullptr || a.beta == nullptr)) return DCX_E_ARG;
     if (pool && ((a.ho | a.wo) & 1)) return DCX_E_SHAPE;
-    const CfgEntry* c = pick(a.n, a.cin, a.ho, a.wo, a.cout_pad, ks, pool, epi);
+    // the fused-head launch must use the tiling dcx_conv_heat_tiles() sized part_val / part_idx for
+    const CfgEntry* c = pick(epi == DCX_EPI_HEAT ? (1 << 20) : a.n, a.cin, a.ho, a.wo, a.cout_pad, ks, pool, epi);
     if (c == nullptr) return DCX_E_SHAPE;
     if (!g_prof || (g_prof_filter >= 0 && g_prof_filter != (int)(c - kCfgs))) return c->launch(a, stream);
     ProfRec r;

@@ -38,10 +38,11 @@ __device__ __forceinline__ dcx_f32x2 dcx_pk_sub(dcx_f32x2 x, dcx_f32x2 y) {
     return r;
 }
 
-template <int WM_, int WN_, int TH_, int TW_, bool POOL_>
+template <int WM_, int WN_, int TH_, int TW_, bool POOL_, int EPI_ = DCX_EPI_BNRELU>
 struct DcxWinoCfg {
     static constexpr int WM = WM_, WN = WN_, TH = TH_, TW = TW_;
     static constexpr bool POOL = POOL_;
+    static constexpr int EPI = EPI_;                   // DCX_EPI_BNRELU or DCX_EPI_HEAT (RefineNet head)
     static constexpr int NTHREADS = WM * WN * 64;
     static constexpr int COUT_TILE = WM * 32;
     static constexpr int PW = TW / 2;                  // output pairs per tile row
@@ -73,6 +74,7 @@ struct DcxWinoCfg {
     static_assert(TILE_PAIRS <= CAP, "tile does not fit the wave layout");
     static_assert(!POOL || (TH % 2 == 0 && TILE_PAIRS <= WN * 32), "pooled tiles must have an even height");
     static_assert(LDS_BYTES * 2 <= 150 * 1024, "LDS tile too large for two workgroups per CU");
+    static_assert(EPI == DCX_EPI_BNRELU || (EPI == DCX_EPI_HEAT && !POOL && WM == 2), "unsupported epilogue");
 };
 
 template <class C>
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
     for (int i = tid; i < cq_pad; i += C::NTHREADS) {
         sP[i] = reinterpret_cast<const float4*>(a.alpha)[i];
         sP[cq_pad + i] = reinterpret_cast<const float4*>(a.beta)[i];
+        if (C::EPI == DCX_EPI_HEAT) sP[2 * cq_pad + i] = reinterpret_cast<const float4*>(a.head_w)[i];
     }
     const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
 
@@ -375,13 +378,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
                 ok1 = ok0 && sx + 1 < a.wo;
                 lane_off = ((unsigned)half * plane + (unsigned)(sy * ws + sx)) * 16u;
             }
-            float4 al[4], be[4];
+            float4 al[4], be[4], hw4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 8 + 2 * g + half;
                 al[g] = sP[cq];
                 be[g] = sP[cq_pad + cq];
+                if (C::EPI == DCX_EPI_HEAT) hw4[g] = sP[2 * cq_pad + cq];
             }
+            float hsum0 = 0.f, hsum1 = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 8 + 2 * g + half;
@@ -410,10 +415,60 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
                 } else {
                     y0.x = dcx_vmax(y0.x, 0.f); y0.y = dcx_vmax(y0.y, 0.f); y0.z = dcx_vmax(y0.z, 0.f); y0.w = dcx_vmax(y0.w, 0.f);
                     y1.x = dcx_vmax(y1.x, 0.f); y1.y = dcx_vmax(y1.y, 0.f); y1.z = dcx_vmax(y1.z, 0.f); y1.w = dcx_vmax(y1.w, 0.f);
+                    if (C::EPI == DCX_EPI_HEAT) {   // 1x1 conv to one channel: this lane's 16 couts, g-major
+                        hsum0 = fmaf(y0.x, hw4[g].x, hsum0); hsum0 = fmaf(y0.y, hw4[g].y, hsum0);
+                        hsum0 = fmaf(y0.z, hw4[g].z, hsum0); hsum0 = fmaf(y0.w, hw4[g].w, hsum0);
+                        hsum1 = fmaf(y1.x, hw4[g].x, hsum1); hsum1 = fmaf(y1.y, hw4[g].y, hsum1);
+                        hsum1 = fmaf(y1.z, hw4[g].z, hsum1); hsum1 = fmaf(y1.w, hw4[g].w, hsum1);
+                        continue;
+                    }
                     if (cq < a.cout_quads) {
                         if (ok0) *reinterpret_cast<float4*>(dst) = y0;
                         if (ok1) *reinterpret_cast<float4*>(dst + 16) = y1;
                     }
+                }
+            }
+            if (C::EPI == DCX_EPI_HEAT) {
+                // refinenet.py:81 convPb + model_utils.py:39-43 arg-max.  The 64 couts of a pixel live in 4 places
+                // (2 half-waves x 2 waves): logit = ((h[wm0,half0] + h[wm0,half1]) + (h[wm1,half0] + h[wm1,half1])) + bias
+                const float t0 = hsum0 + __shfl_xor(hsum0, 32), t1 = hsum1 + __shfl_xor(hsum1, 32);
+                __syncthreads();   // every wave is done reading sB[buf]: its head becomes reduction scratch
+                float* scr = reinterpret_cast<float*>(sB + buf * LDSF);
+                if (wm == 1 && half == 0) { scr[(wn * 32 + l31) * 2] = t0; scr[(wn * 32 + l31) * 2 + 1] = t1; }
+                __syncthreads();
+                float best = -INFINITY;
+                int besti = 0x7fffffff;
+                if (wm == 0) {
+                    const float l0 = (t0 + scr[(wn * 32 + l31) * 2]) + a.head_b;
+                    const float l1 = (t1 + scr[(wn * 32 + l31) * 2 + 1]) + a.head_b;
+                    if (ok0) {
+                        const int idx = sy * a.wo + sx;
+                        if (a.heat != nullptr && half == 0) a.heat[((size_t)cur.n * a.ho + sy) * a.wo + sx] = l0;
+                        best = l0; besti = idx;
+                        if (ok1) {
+                            if (a.heat != nullptr && half == 0) a.heat[((size_t)cur.n * a.ho + sy) * a.wo + sx + 1] = l1;
+                            if (l1 > best) { best = l1; besti = idx + 1; }
+                        }
+                    }
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        const float ov = __shfl_xor(best, off);
+                        const int oi = __shfl_xor(besti, off);
+                        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                    }
+                }
+                float* red_v = scr + 256;
+                int* red_i = reinterpret_cast<int*>(scr) + 256 + 16;
+                if (wm == 0 && lane == 0) { red_v[wn] = best; red_i[wn] = besti; }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int wv = 1; wv < WN; ++wv) {
+                        const float ov = red_v[wv];
+                        const int oi = red_i[wv];
+                        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                    }
+                    a.part_val[(size_t)cur.n * tiles + cur.ty * a.tiles_x + cur.tx] = best;
+                    a.part_idx[(size_t)cur.n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
                 }
             }
         }
@@ -448,7 +503,9 @@ static int dcx_conv_wino_launch_cfg(DcxConvArgs a, hipStream_t stream) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES + 8192)));
         attr_set = true;
     }
-    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 8;   // transformed-tile double buffer + alpha, beta2
+    if (C::EPI == DCX_EPI_HEAT && (a.head_w == nullptr || a.part_val == nullptr || a.part_idx == nullptr)) return DCX_E_ARG;
+    if (C::EPI != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
+    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 12;   // transformed-tile double buffer + alpha, beta2, head weights
     if (lds > 160 * 1024) return DCX_E_SHAPE;
     hipLaunchKernelGGL((dcx_conv_wino_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), lds, stream, a);
     return (int)hipGetLastError();
