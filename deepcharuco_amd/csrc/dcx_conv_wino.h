@@ -13,9 +13,10 @@
 // GEMM view: four independent GEMMs (one per position p), M = cout, N = output pairs, K = 3 * cin.  A lane owns one
 // output PAIR and keeps the four partial sums m_p in four accumulators, so the output transform, BN, ReLU and the
 // horizontal half of the 2x2 max-pool are in-lane.  The transformed input tile lives in LDS as
-// sV[buf][p][cq][row][pair] float4: the input transform is applied while staging (4 buffer loads, 8 v_pk_add_f32,
-// 4 ds_write_b128 per piece), the k-loop itself is the same VALU-free MFMA stream as in the direct kernel, with
-// "tap" = (ky, p): 12 weight planes instead of 9.
+// sV[buf][p][cq][row][pair] float4.  Staging is two passes (every global load lane-contiguous): raw float4 -> sR, one
+// extra barrier, then per (cq, row, pair) piece 4 ds_read_b128, 8 v_pk_add_f32, 4 ds_write_b128.  The k-loop is the same
+// MFMA stream as in the direct kernel with "tap" = (ky, p): 12 weight planes instead of 9, and it is ONE basic block
+// per unit (no per-instruction conditions: measured ~500 cycles per unit when they were there).
 //
 // Summation order (restated bit-exactly by oracle/conv_exact.c: dcx_conv_wino_exact):
 //   m_p = 0;  for chunk c (16 cin) / ky / s in 0..1 / j in 0..3:
@@ -25,6 +26,8 @@
 // inside the 1e-4 logit margin of the parity policy (tests/test_gpu_parity.py).
 #pragma once
 #include "dcx_conv_mfma.h"
+
+#include <type_traits>
 
 // one v_pk_add_f32 (hipcc scalarises float2 +/- into two v_add_f32; every VALU instruction in the k-loop costs matrix time)
 __device__ __forceinline__ dcx_f32x2 dcx_pk_add(dcx_f32x2 x, dcx_f32x2 y) {
@@ -52,28 +55,31 @@ struct DcxWinoCfg {
     static constexpr int PLANE = HH * PW;              // float4 per (position, channel quad)
     static constexpr int CQC = DCX_CCH / 4;
     static constexpr int PIECES = CQC * PLANE;         // staging work items per unit: (cq, row, pair)
-    static constexpr int ITER = (PIECES + NTHREADS - 1) / NTHREADS;
-    static constexpr int PSTRIDE = ITER * NTHREADS;    // float4 between position planes: padded so that every thread
-                                                       // writes every piece slot (no divergent branch in the k-loop)
-    static constexpr int LDS_FLOAT4 = 4 * PSTRIDE;     // one buffer: 4 positions
-    static constexpr size_t LDS_BYTES = (size_t)2 * LDS_FLOAT4 * 16;
+    static constexpr int ITER = (PIECES + NTHREADS - 1) / NTHREADS;   // transform pieces per thread per unit
+    static constexpr int DUP = ITER * NTHREADS - PIECES;   // threads past the last piece redo pieces [PIECES-DUP, PIECES):
+                                                           // same values written twice, no divergent branch in the k-loop
+    static constexpr int PSTRIDE = PIECES;             // float4 between position planes
+    static constexpr int LDS_FLOAT4 = 4 * PSTRIDE;     // one transformed buffer: 4 positions
+    static constexpr int RW = TW + 8;                  // raw columns per staged row: [x0-4, x0+TW+4) although the conv needs
+                                                       // [x0-1, x0+TW+1): with 4-pixel margins every group of 4 lanes maps to
+                                                       // one ALIGNED 64-B block (misaligned groups cost ~4x address-path time)
+    static constexpr int RAW = CQC * HH * RW;          // raw float4 of the tile (one 16-channel chunk)
+    static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;   // raw float4 per thread per unit
+    static constexpr int RAW_PAD = ITER_R * NTHREADS;  // raw buffer incl. padding slots (they receive zeros)
+    static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_PAD) * 16;   // 2 transformed buffers + 1 raw buffer
     static constexpr int STEPS = 3 * (DCX_CCH / 8);    // k-steps per unit: (ky, 8-channel group)
 #ifndef DCX_WINO_DA
 #define DCX_WINO_DA 2
 #endif
     static constexpr int DA = DCX_WINO_DA;             // weights are requested DA k-steps ahead
-#ifndef DCX_WINO_DP
-#define DCX_WINO_DP 3
-#endif
-    static constexpr int DP = DCX_WINO_DP;             // a staging piece is transformed + written DP k-steps after its loads
-    static constexpr int LOAD_STEPS = STEPS - DP;
-    static constexpr int PPS = (ITER + LOAD_STEPS - 1) / LOAD_STEPS;
+    static constexpr int RAW_STORE_STEP = 3;           // raw loads are issued in k-step 0 and written to LDS in this step
     static constexpr int NPAIR = 8;                    // 16 MFMAs per k-step: 4 registers j x 4 positions p
     static constexpr int OCC = 2;
     static_assert(TW % 2 == 0, "tile width must be even");
     static_assert(TILE_PAIRS <= CAP, "tile does not fit the wave layout");
     static_assert(!POOL || (TH % 2 == 0 && TILE_PAIRS <= WN * 32), "pooled tiles must have an even height");
     static_assert(LDS_BYTES * 2 <= 150 * 1024, "LDS tile too large for two workgroups per CU");
+    static_assert(ITER <= 2 && ITER_R <= 4 && STEPS == 6 && DUP <= NTHREADS, "k-loop schedule assumes <= 2 transform pieces and <= 4 raw float4 per thread");
     static_assert(EPI == DCX_EPI_BNRELU || (EPI == DCX_EPI_HEAT && !POOL && WM == 2), "unsupported epilogue");
 };
 
@@ -81,7 +87,7 @@ template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(const DcxConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sB[];
     constexpr int WN = C::WN, PW = C::PW, PLANE = C::PLANE, PIECES = C::PIECES, PSTRIDE = C::PSTRIDE;
-    constexpr int STEPS = C::STEPS, ITER = C::ITER, PPS = C::PPS, LDSF = C::LDS_FLOAT4, CQC = C::CQC;
+    constexpr int STEPS = C::STEPS, ITER = C::ITER, ITER_R = C::ITER_R, RW = C::RW, LDSF = C::LDS_FLOAT4, CQC = C::CQC;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,22 +166,39 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
 #pragma unroll
         for (int p = 0; p < 4; ++p) dst[p] = load_b1(buf, step, p);
     };
-    // staging piece pi = (cq, row, pair) #(tid + pi*NTHREADS): four input pixels (tile-relative columns 2*pair + e)
-    int p_hy[ITER], p_hx[ITER];
-    unsigned p_rel[ITER][4];
+    // Staging is two passes through LDS so that every global load is lane-contiguous (16-B loads at a 32-B lane
+    // stride cost ~4x the address-path time, measured):
+    //   raw pass:   float4 #(tid + k*NTHREADS) of the raw [cq][row][RW] tile -> sR (exactly the direct kernel's staging:
+    //               per-piece constant offset relative to the tile origin, hardware out-of-range -> 0.0f)
+    //   transform:  piece (cq, row, pair) reads its four raw pixels 2*pair + e from sR, applies B^T d, writes the four
+    //               position planes of the next unit's transformed buffer
+    const int xs = 4 - a.pad;                   // raw column of the first input column the convolution needs
+    int r_hy[ITER_R], r_hx[ITER_R];
+    unsigned r_rel[ITER_R];
+#pragma unroll
+    for (int k = 0; k < ITER_R; ++k) {
+        const int idx = tid + k * C::NTHREADS;
+        const int cq = idx / (C::HH * RW);
+        const int hp = idx - cq * (C::HH * RW);
+        r_hy[k] = hp / RW;
+        r_hx[k] = hp - r_hy[k] * RW;
+        r_hx[k] -= xs;      // column relative to the tile's first needed input column (sx0): -3-.. +TW+4..
+        const int prow = ((r_hy[k] - a.pad) >> a.ups) + a.pad, pcol = ((r_hx[k] - a.pad) >> a.ups) + a.pad;
+        // the margin columns exist only to align the lane groups: they are never read back, so they are not fetched
+        const bool needed = idx < C::RAW && r_hx[k] >= 0 && r_hx[k] < C::TW + 2;
+        r_rel[k] = needed ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
+    }
+    float4* sR = sB + 2 * LDSF;                 // raw buffer (single: written in k-step 3, read in k-steps 4, 5)
+    int t_src[ITER], t_dst[ITER];               // transform piece: raw index of its first pixel, index inside a position plane
 #pragma unroll
     for (int pi = 0; pi < ITER; ++pi) {
-        const int idx = tid + pi * C::NTHREADS;
+        int idx = tid + pi * C::NTHREADS;
+        if (idx >= PIECES) idx -= C::DUP;
         const int cq = idx / PLANE;
         const int hp = idx - cq * PLANE;
-        p_hy[pi] = hp / PW;
-        p_hx[pi] = 2 * (hp - p_hy[pi] * PW);
-        const int prow = ((p_hy[pi] - a.pad) >> a.ups) + a.pad;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int pcol = ((p_hx[pi] + e - a.pad) >> a.ups) + a.pad;
-            p_rel[pi][e] = idx < PIECES ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
-        }
+        const int row = hp / PW, pr = hp - row * PW;
+        t_src[pi] = (cq * C::HH + row) * RW + 2 * pr + xs;
+        t_dst[pi] = idx;
     }
     auto unit_rsrc = [&](const DcxItem& it, int c) {
         const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
@@ -185,29 +208,27 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
     };
     auto tile_interior = [&](const DcxItem& it) {
         const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
-        return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + C::TW + 2 <= wl;
+        return sy0 >= 0 && sx0 - xs >= 0 && sy0 + C::HH <= hl && sx0 - xs + RW <= wl;
     };
     auto stage_fetch = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
         const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
-    // input transform of one piece, one position at a time: 2 v_pk_add_f32 + 1 ds_write_b128 (position planes are
-    // PSTRIDE float4 apart; slots past the end of the tile are padding and receive the zeros their loads returned)
-    auto stage_store_p = [&](float4* wbase_lds, int pi, int p, const float4 (&d)[4]) {
+    // input transform of one piece, one position at a time: 2 v_pk_add_f32 + 1 ds_write_b128
+    auto xform_p = [&](int p, const float4 (&d)[4]) {
         const float4& x = p == 0 ? d[0] : p == 1 ? d[1] : p == 2 ? d[2] : d[1];
         const float4& y = p == 0 ? d[2] : p == 1 ? d[2] : p == 2 ? d[1] : d[3];
         // packed fp32 (two lanes of the float4 per VALU instruction): v_pk_add_f32 with a neg modifier for the differences
         const dcx_f32x2 xl = {x.x, x.y}, xh = {x.z, x.w}, yl = {y.x, y.y}, yh = {y.z, y.w};
         const dcx_f32x2 lo = p == 1 ? dcx_pk_add(xl, yl) : dcx_pk_sub(xl, yl), hi = p == 1 ? dcx_pk_add(xh, yh) : dcx_pk_sub(xh, yh);
-        wbase_lds[pi * C::NTHREADS + p * PSTRIDE] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
     };
-    auto stage_store_at = [&](float4* wbase_lds, int pi, const float4 (&d)[4]) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) stage_store_p(wbase_lds, pi, p, d);
+    auto stage_store_p = [&](float4* vbuf, int pi, int p, const float4 (&d)[4]) {
+        vbuf[t_dst[pi] + p * C::PSTRIDE] = xform_p(p, d);
     };
 
     // ---- epilogue constants in LDS: sP[0] alpha, sP[1] beta2 ---------------------------------------------
-    float4* sP = sB + 2 * LDSF;
+    float4* sP = sB + 2 * LDSF + C::RAW_PAD;
     const int cq_pad = a.cout_pad >> 2;
     for (int i = tid; i < cq_pad; i += C::NTHREADS) {
         sP[i] = reinterpret_cast<const float4*>(a.alpha)[i];
@@ -233,16 +254,19 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
         const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(cur, 0);
         const int sy0 = cur.ty * C::TH - a.pad, sx0 = cur.tx * C::TW - a.pad;
 #pragma unroll
+        for (int k = 0; k < ITER_R; ++k) {
+            const int ly = sy0 + r_hy[k], lx = sx0 + r_hx[k];
+            const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+            sR[tid + k * C::NTHREADS] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
+        }
+        __syncthreads();
+#pragma unroll
         for (int pi = 0; pi < ITER; ++pi) {
             float4 d[4];
-            const int ly = sy0 + p_hy[pi];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int lx = sx0 + p_hx[pi] + e;
-                const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
-                d[e] = stage_fetch(r0, inb ? p_rel[pi][e] : 0x80000000u);
-            }
-            stage_store_at(sB + tid, pi, d);
+            for (int e = 0; e < 4; ++e) d[e] = sR[t_src[pi] + e];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) stage_store_p(sB, pi, p, d);
         }
     }
 
@@ -270,33 +294,23 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
             for (int d = 0; d < C::DA; ++d) aq[d][p] = a_c[d][p];
         float4 bq[STEPS + 1][4];
         load_b(buf, 0, bq[0]);
-        float4* lds_w = sB + (buf ^ 1) * LDSF + tid;
-        float4 pv[STEPS][PPS][4];
+        float4* vnext = sB + (buf ^ 1) * LDSF;      // transformed buffer of the next unit
+        float4 rv[ITER_R];                           // raw float4 in flight (k-step 0 -> RAW_STORE_STEP)
+        float4 td[4];                                // the four raw pixels of the piece being transformed
+        float4 tv;                                   // transformed position waiting for its LDS write
         const bool n_interior = tile_interior(nxt);
-        bool p_in[PPS][4];
-        unsigned poff[PPS][4];
-        auto off_part = [&](int part, int for_step) {
-            if (for_step >= C::LOAD_STEPS) return;
+        // raw-load offsets of the next unit: the per-piece constants, or (border tiles, ONE uniform branch per unit) the
+        // bounds-checked ones
+        unsigned roff[ITER_R];
 #pragma unroll
-            for (int k = 0; k < PPS; ++k) {
-                const int pi = for_step * PPS + k;
-                if (pi >= ITER) continue;
-                if (n_interior) {
-                    if (part == 1) {
+        for (int k = 0; k < ITER_R; ++k) roff[k] = r_rel[k];
+        if (!n_interior) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) poff[k][e] = p_rel[pi][e];
-                    }
-                } else if (part == 0) {
-                    const int ly = nsy0 + p_hy[pi];
-                    const bool rok = (unsigned)ly < (unsigned)hl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) p_in[k][e] = rok && (unsigned)(nsx0 + p_hx[pi] + e) < (unsigned)wl;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) poff[k][e] = p_in[k][e] ? p_rel[pi][e] : 0x80000000u;
-                }
+            for (int k = 0; k < ITER_R; ++k) {
+                const int ly = nsy0 + r_hy[k], lx = nsx0 + r_hx[k];
+                roff[k] = ((unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl) ? r_rel[k] : 0x80000000u;
             }
-        };
+        }
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             int pair = 0;
@@ -308,22 +322,20 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
                     const float4 av4 = aq[step][p], bv4 = bq[step][p];
                     const float av = j == 0 ? av4.x : j == 1 ? av4.y : j == 2 ? av4.z : av4.w;
                     const float bv = j == 0 ? bv4.x : j == 1 ? bv4.y : j == 2 ? bv4.z : bv4.w;
-                    if (step == 0 && j == 0 && c == 0) {
-                        const dcx_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, zero, 0, 0, 0);
-                    } else {
-                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
-                    }
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
                 }
                 ++pair;
                 __builtin_amdgcn_sched_barrier(0);
             };
-            // eight slots, one before each MFMA pair (the pair before it covers its issue time); every slot holds at
-            // most one LDS read, one weight load, one staging load and one transform+write, so no slot is long enough
-            // to drain the matrix pipe:
-            //   slots 0..3: B(step+1, p = slot), A(step+DA, p = slot); slots 2, 3 also this step's staging offsets
-            //   slots 4..7: staging load e = slot-4 of this step's piece; transform + write of position p = slot-4 of
-            //               the piece requested DP steps ago
+            // The k-loop of a unit is ONE basic block (no condition inside it: per-instruction branches on "first chunk" or
+            // "border tile" cost ~500 cycles per unit).  Eight slots, one before each MFMA pair (the pair before it covers
+            // its issue time); a slot holds at most one LDS read, one weight load and one staging operation:
+            //   slots 0..3: B(step+1, p = slot), A(step+DA, p = slot)
+            //   k-step 0, slots 4..7: load raw float4 #(slot-4) of the next unit
+            //   k-step 3, slots 4..7: raw float4 #(slot-4) -> sR;   then ONE extra barrier before k-step 4
+            //   k-steps 4, 5 (transform piece 0, 1): slots 0..3 read raw pixel e = slot from sR, slots 4..7 transform and
+            //               write position p = slot-4 into the next unit's buffer
+            if (step == C::RAW_STORE_STEP + 1) __syncthreads();   // the raw tile is complete in sR
 #pragma unroll
             for (int slot = 0; slot < 8; ++slot) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -331,22 +343,16 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
                     if (step + 1 < STEPS) bq[step + 1][slot] = load_b1(buf, step + 1, slot);
                     if (step + C::DA < STEPS) aq[step + C::DA][slot] = load_a1(wb_cur, step + C::DA, slot);
                     else aq[step + C::DA][slot] = load_a1(wb_nxt, step + C::DA - STEPS, slot);
-                    if (slot >= 2) off_part(slot - 2, step);   // this step's piece (requested in slots 4..7)
+                    if (step >= STEPS - ITER) td[slot] = sR[t_src[step >= STEPS - ITER ? step - (STEPS - ITER) : 0] + slot];
                 } else {
                     const int e = slot - 4;
-                    if (step < C::LOAD_STEPS) {
-#pragma unroll
-                        for (int k = 0; k < PPS; ++k) {
-                            const int pi = step * PPS + k;
-                            if (pi < ITER) pv[step][k][e] = stage_fetch(rs_n, poff[k][e]);
-                        }
-                    }
-                    if (step >= C::DP) {
-#pragma unroll
-                        for (int k = 0; k < PPS; ++k) {
-                            const int pi = (step - C::DP) * PPS + k;
-                            if (pi < ITER) stage_store_p(lds_w, pi, e, pv[step - C::DP][k]);
-                        }
+                    if (step == 0 && e < ITER_R) rv[e] = stage_fetch(rs_n, roff[e]);
+                    if (step == C::RAW_STORE_STEP && e < ITER_R) sR[tid + e * C::NTHREADS] = rv[e];
+                    if (step >= STEPS - ITER) {   // the write of a position is issued one slot after its two adds
+                        const int tpi = step >= STEPS - ITER ? step - (STEPS - ITER) : 0;
+                        if (e > 0) vnext[t_dst[tpi] + (e - 1) * C::PSTRIDE] = tv;
+                        tv = xform_p(e, td);
+                        if (e == 3) vnext[t_dst[tpi] + 3 * C::PSTRIDE] = tv;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -471,6 +477,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
                     a.part_idx[(size_t)cur.n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
                 }
             }
+        }
+
+        if (c == nch - 1) {   // next unit starts a new work item
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
         }
 
         if (!has_next) {

@@ -22,6 +22,12 @@ def per_kernel(path, counter):
 
 
 def lib_name(rocprof_name):
+    m = re.search(r"DcxWinoCfg<([^>]*)>", rocprof_name)
+    if m:   # <WM, WN, TH, TW, POOL, EPI> -> the name dcx_profile_kernel_name() reports
+        f = [x.strip() for x in m.group(1).split(",")]
+        f[4] = "1" if f[4] == "true" else "0"
+        epi = f[5] if len(f) > 5 else "0"
+        return "dcx_conv_wino_kernel<DcxWinoCfg<" + ",".join(f[:5]) + (",DCX_EPI_HEAT" if epi == "2" else "") + ">>"
     m = re.search(r"DcxConvCfg<([^>]*)>", rocprof_name)
     if not m:
         return None

@@ -29,8 +29,8 @@ else
     python tools/rocprof_summary.py gpurun_out/prof_r${R}/r${R}_results.db | cut -c1-220 > profiles/r${R}_kernel_stats.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_fetch/fetch_results.db dcx_ > profiles/r${R}_pmc_fetch_size.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_write/write_results.db dcx_ > profiles/r${R}_pmc_write_size.txt
-    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_sq/sq_results.db dcx_conv_mfma > profiles/r${R}_pmc_sq.txt
-    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_lds/lds_results.db dcx_conv_mfma > profiles/r${R}_pmc_lds_valu.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_sq/sq_results.db dcx_conv > profiles/r${R}_pmc_sq.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_lds/lds_results.db dcx_conv > profiles/r${R}_pmc_lds_valu.txt
     grep '^{' gpurun_out/bench.log > profiles/r${R}_bench_n1.json
     ls -la profiles/
 fi

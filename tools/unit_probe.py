@@ -8,7 +8,7 @@ from deepcharuco_amd.models.net import dcModel, lModel
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
 dev = torch.device("cuda", 0)
 L = _lib.lib()
-B = 32
+B = int(os.environ.get("PROBE_B", "32"))
 frames = torch.from_numpy(W.synthetic_frames("board", 1000, B, 240, 320)).to(dev)
 sd = W.synthetic_state_dict("detector", 1234); sd["convDb.bias"][16] += np.float32(3.0)
 dc, rn = lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
