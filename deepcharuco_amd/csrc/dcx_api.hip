@@ -42,6 +42,29 @@ std::vector<float> pack_conv_wino(const float* w, int cout, int cin, int cout_pa
     return out;
 }
 
+// 3x3 OIHW -> 2-D Winograd F(2x2,3x3): [xi*4 + nu][cin/4][cout_pad][4], U = G g G^T in fp32, rows (ky) first, then columns
+// (dcx_conv_wino2.h; restated by oracle/conv_exact.c).
+std::vector<float> pack_conv_wino2(const float* w, int cout, int cin, int cout_pad) {
+    const int cq = cin / 4;
+    std::vector<float> out((size_t)16 * cq * cout_pad * 4, 0.0f);
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i) {
+            const float* g = w + ((size_t)o * cin + i) * 9;
+            float h[4][3], u[4][4];
+            for (int kx = 0; kx < 3; ++kx) {
+                const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+                h[0][kx] = g0; h[1][kx] = ((g0 + g1) + g2) * 0.5f; h[2][kx] = ((g0 - g1) + g2) * 0.5f; h[3][kx] = g2;
+            }
+            for (int xi = 0; xi < 4; ++xi) {
+                u[xi][0] = h[xi][0]; u[xi][1] = ((h[xi][0] + h[xi][1]) + h[xi][2]) * 0.5f;
+                u[xi][2] = ((h[xi][0] - h[xi][1]) + h[xi][2]) * 0.5f; u[xi][3] = h[xi][2];
+            }
+            for (int pos = 0; pos < 16; ++pos)
+                out[(((size_t)pos * cq + (i >> 2)) * cout_pad + o) * 4 + (i & 3)] = u[pos >> 2][pos & 3];
+        }
+    return out;
+}
+
 // eval-mode BatchNorm2d as ATen's CPU inference path evaluates it: y = x * alpha + beta with
 // alpha = gamma * (1 / sqrt(var + eps)), beta = bn_bias - mean * alpha   (fp32 throughout).
 void fold_bn(const float* gamma, const float* bbeta, const float* mean, const float* var, int c, int c_pad,
@@ -65,6 +88,7 @@ std::vector<float> pad_vec(const float* v, int c, int c_pad) {
 struct DevLayer {       // one MFMA convolution's parameters on the device
     float* w = nullptr;
     float* w_wino = nullptr;   // 3x3 + BN layers only
+    float* w_wino2 = nullptr;  // 3x3 + BN layers only
     float* bias = nullptr;
     float* alpha = nullptr;
     float* beta = nullptr;
@@ -80,6 +104,7 @@ int upload(const std::vector<float>& h, float** d) {
 void free_layer(DevLayer& l) {
     if (l.w) (void)hipFree(l.w);
     if (l.w_wino) (void)hipFree(l.w_wino);
+    if (l.w_wino2) (void)hipFree(l.w_wino2);
     if (l.bias) (void)hipFree(l.bias);
     if (l.alpha) (void)hipFree(l.alpha);
     if (l.beta) (void)hipFree(l.beta);
@@ -106,6 +131,7 @@ int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out) {
         rc = upload(al, &l.alpha);
         if (rc == 0) rc = upload(be, &l.beta);
         if (rc == 0 && ks == 3) rc = upload(pack_conv_wino(h.w, cout, cin, l.cout_pad), &l.w_wino);
+        if (rc == 0 && ks == 3) rc = upload(pack_conv_wino2(h.w, cout, cin, l.cout_pad), &l.w_wino2);
     }
     if (rc != 0) { free_layer(l); return rc; }
     *out = l;
@@ -201,7 +227,7 @@ DcxConvArgs conv_args(const DevLayer& l, const float* in, int n, int in_cq_total
                       int ups, int pad, float* out, int out_cq_total, const int* n_limit) {
     DcxConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
+    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.w_wino2 = l.w_wino2; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
     a.n_limit = n_limit;
     a.n = n; a.in_cq_total = in_cq_total; a.in_cq_off = in_cq_off; a.cin = l.cin;
     a.hin = hin; a.win = win; a.ups = ups; a.pad = pad;

@@ -26,6 +26,7 @@ struct DcxConvArgs {
     const float* in;       // C4 [N][in_cq_total][Hin][Win][4]
     const float* w;        // packed [ks*ks][cin/4][cout_pad][4]   (4 = cin % 4)
     const float* w_wino;   // nullable; 3x3 + BN layers: F(2,3)-transformed weights [ky*4 + p][cin/4][cout_pad][4] (dcx_conv_wino.h)
+    const float* w_wino2;  // nullable; same layers: F(2x2,3x3)-transformed weights [xi*4 + nu][cin/4][cout_pad][4] (dcx_conv_wino2.h)
     const float* bias;     // [cout_pad]
     const float* alpha;    // [cout_pad]  gamma / sqrt(var + eps)
     const float* beta;     // [cout_pad]  bn_beta - mean * alpha

@@ -1,6 +1,7 @@
 // dcx_conv_mfma.hip -- instantiations and tile selection for the MFMA convolution kernel.
 #include "dcx_conv_mfma.h"
 #include "dcx_conv_wino.h"
+#include "dcx_conv_wino2.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -11,7 +12,7 @@ namespace {
 struct CfgEntry {
     int cout_tile, cap, th, tw, ks, pool, epi, acc_tiles;
     int inlane;   // pooled layout with the 2x2 window inside one lane (MT=1, NT=4): no cross-lane max
-    int wino;     // 1-D Winograd F(2,3) kernel (dcx_conv_wino.h): 12 instead of 18 k-steps per 16 channels
+    int wino;     // 1: 1-D Winograd F(2,3) kernel (dcx_conv_wino.h), 2/3 of the MFMAs; 2: 2-D F(2x2,3x3) (dcx_conv_wino2.h), 4/9
     int (*launch)(DcxConvArgs, hipStream_t);
     const char* name;
 };
@@ -29,6 +30,16 @@ struct CfgEntry {
     { WM * 32, WN * 64, TH, TW, 3, 0, DCX_EPI_HEAT, 4, 0, 1,                                               \
       &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, false, DCX_EPI_HEAT>>,                          \
       "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW ",0,DCX_EPI_HEAT>>" }
+
+#define DCX_W2CFG(TH, TW, POOL)                                                                       \
+    { 64, 256, TH, TW, 3, POOL, DCX_EPI_BNRELU, 16, 0, 2,                                                   \
+      &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, (POOL) != 0>>,                                        \
+      "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW "," #POOL ">>" }
+
+#define DCX_W2CFG_HEAT(TH, TW)                                                                        \
+    { 64, 256, TH, TW, 3, 0, DCX_EPI_HEAT, 16, 0, 2,                                                        \
+      &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, false, DCX_EPI_HEAT>>,                                \
+      "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW ",0,DCX_EPI_HEAT>>" }
 
 // Wave layouts:  A = 1x4 waves, 64 couts x 256 px   B = 2x2 waves, 128 couts x 128 px
 //                C = 4x1 waves, 128 couts x 64 px
@@ -68,7 +79,20 @@ const CfgEntry kCfgs[] = {
     DCX_WCFG(2, 2, 8, 16, 1),
     DCX_WCFG(2, 2, 6, 20, 1),
     DCX_WCFG_HEAT(2, 2, 4, 32),
+    // 2-D Winograd F(2x2,3x3): 64 couts x 64 2x2-tiles, 256 accumulator registers, one workgroup per CU
+    DCX_W2CFG(16, 16, 0),
+    DCX_W2CFG(8, 32, 0),
+    DCX_W2CFG(6, 40, 0),      // 30x40 maps: 3 x 20 tiles
+    DCX_W2CFG(16, 16, 1),
+    DCX_W2CFG(8, 32, 1),
+    // (the 2-D head variant works -- DCX_W2CFG_HEAT(16, 16) -- but its epilogue spills and it measured slower than the 1-D head)
 };
+
+int dcx_wino2_enabled() {   // on by default; DCX_WINO2=0 keeps the 1-D Winograd / direct kernels (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_WINO2"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v;
+}
 
 int dcx_wino_enabled() {   // on by default; DCX_WINO=0 keeps every layer on the direct kernels (A/B runs)
     static int v = -1;
@@ -110,7 +134,8 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         if (c.ks != ks || c.pool != pool || c.epi != epi) continue;
         if (cout_pad % c.cout_tile != 0) continue;
         if (c.inlane && !dcx_inlane_pool_enabled()) continue;
-        if (c.wino && !dcx_wino_enabled()) continue;
+        if (c.wino == 1 && !dcx_wino_enabled()) continue;
+        if (c.wino == 2 && !dcx_wino2_enabled()) continue;
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
         if (c.cap > 256 && (dcx_big_tiles_disabled() || (double)ho * wo / ((double)tiles * c.cap) < 0.999)) continue;
         const double items = (double)n * (cout_pad / c.cout_tile) * tiles;
@@ -118,8 +143,10 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         const int steps = (c.wino ? 3 : ks * ks) * (DCX_CCH / 8);   // Winograd: (ky, 8 channels), 4 positions inside the step
         // per-unit overhead: barrier + first LDS wait + bookkeeping (520); the Winograd units also pay their input
         // transform and the scattered staging loads inside the k-loop (measured ~1100 per unit, tools/unit_probe.py)
-        const double item_cost = (double)units * steps * (4 * c.acc_tiles) * 64.0 + units * (c.wino ? 1100.0 : 520.0)
-                               + c.acc_tiles * 16 * (c.wino ? 25.0 : c.inlane ? 35.0 : (pool ? 60.0 : 40.0));
+        double item_cost = (double)units * steps * (4 * c.acc_tiles) * 64.0 + units * (c.wino ? 1100.0 : 520.0)
+                         + c.acc_tiles * 16 * (c.wino ? 25.0 : c.inlane ? 35.0 : (pool ? 60.0 : 40.0));
+        if (c.wino == 2)   // 128 MFMAs per unit, one workgroup per CU: nothing hides the transform / barrier / epilogue
+            item_cost = (double)units * (128 * 64.0 + 1950.0) + 6200.0;   // measured: k-loop 9,700, barrier + bookkeeping 420, epilogue 6,200
         const double rounds = (double)(((long)items + n_cu - 1) / n_cu);
         double cost = rounds * item_cost;
         if (c.cout_tile == 64 && c.cap == 256) cost *= 0.999;   // deterministic tie-break towards the A layout

@@ -1,0 +1,498 @@
+// dcx_conv_wino2.h -- 3x3 convolution + BN + ReLU (+2x2 max-pool) (+RefineNet head) with the 2-D Winograd transform
+// F(2x2, 3x3) on the gfx950 fp32 matrix cores: 16 products per 2x2 output tile and input channel instead of 36, i.e.
+// 4/9 of the direct convolution's MFMAs (the 1-D variant in dcx_conv_wino.h executes 2/3).  Read dcx_conv_mfma.h and
+// dcx_conv_wino.h first; layouts, persistent work walk and staging scheme are the same.
+//
+//   per 2x2 output tile (rows 2ty, 2ty+1; columns 2tx, 2tx+1) and input channel, d = the 4x4 input window whose top-left
+//   pixel is (2ty - pad, 2tx - pad):
+//     rows     t[xi][c] :  t0 = d[0][c]-d[2][c]   t1 = d[1][c]+d[2][c]   t2 = d[2][c]-d[1][c]   t3 = d[1][c]-d[3][c]
+//     columns  v[xi][nu]:  v0 = t[xi][0]-t[xi][2] v1 = t[xi][1]+t[xi][2] v2 = t[xi][2]-t[xi][1] v3 = t[xi][1]-t[xi][3]
+//     weights  u = G g G^T, transformed on the host in fp32 (rows first, then columns; h1 = ((h0+h1)+h2)*0.5f ...)
+//     m[xi][nu] += u[xi][nu] * v[xi][nu]                                   (16 accumulators = 256 registers per lane)
+//     y[i][j] = sum over (xi, nu), xi-major ascending, of AT[i][xi]*AT[j][nu]*m[xi][nu],  AT = [[1,1,1,0],[0,1,-1,-1]]
+//               (sequential adds / subtracts; the first non-zero term initialises)
+//
+// GEMM view: 16 independent GEMMs, M = cout, N = tiles, K = cin.  A wave owns 32 couts x 32 tiles x 16 positions; its
+// 256 accumulator registers live in AGPRs (one workgroup of 4 waves per CU, the whole 512-register file per lane);
+// workgroup = 64 couts x 64 tiles (16x16 or 8x32 output pixels).  Summation order of every m (restated bit-exactly by
+// oracle/conv_exact.c: dcx_oracle_conv_wino2_exact):
+//   m = 0;  for chunk c (16 cin) / s in 0..1 / j in 0..3:  m = fmaf(u[8s+j], v[8s+j], m);  m = fmaf(u[8s+4+j], v[8s+4+j], m)
+//
+// Unit = 16 channels = 2 k-steps x 16 positions x 4 MFMAs = 8192 matrix cycles.  Operands are prefetched at position
+// granularity (weights from L2, transformed activations from LDS, DQ positions ahead); the next unit's raw tile is
+// loaded early in the unit, written to sR in the middle, and transformed in the second half (per thread 16 ds_read_b128,
+// 64 v_pk_add_f32, 16 ds_write_b128), one micro-step per MFMA pair.  The unit body is one basic block.
+#pragma once
+#include "dcx_conv_wino.h"
+
+template <int TH_, int TW_, bool POOL_, int EPI_ = DCX_EPI_BNRELU>
+struct DcxWino2Cfg {
+    static constexpr int TH = TH_, TW = TW_;
+    static constexpr bool POOL = POOL_;
+    static constexpr int EPI = EPI_;
+    static constexpr int NTHREADS = 256;
+    static constexpr int COUT_TILE = 64;
+    static constexpr int TY = TH / 2, TX = TW / 2;         // 2x2 output tiles of the workgroup tile
+    static constexpr int NTILES = TY * TX;                 // <= 64
+    static constexpr int HH = TH + 2, RW = TW + 2;         // raw input rows / columns
+    static constexpr int CQC = DCX_CCH / 4;
+    static constexpr int RAW = CQC * HH * RW;
+    static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;
+    static constexpr int RAW_PAD = ITER_R * NTHREADS;
+    static constexpr int VPLANE = CQC * 64;                // float4 per position: [cq][tile]
+    static constexpr int LDS_FLOAT4 = 16 * VPLANE;         // one transformed buffer
+    static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_PAD) * 16;
+    static constexpr int NQ = 2 * 16;                      // (k-step, position) pairs per unit
+    // operand prefetch distances in positions (256 matrix cycles each).  Weights share the vector-memory return queue with
+    // the raw staging loads, which come from HBM: loads return in order, so a weight load issued behind them arrives after
+    // them -- its distance must cover HBM latency (measured: 4 positions cost 1,500 cycles per unit).  LDS reads do not.
+    static constexpr int DQ = 8;                           // weights (A)
+    static constexpr int DQB = 4;                          // transformed activations (B)
+    // staging schedule in events (one per MFMA pair: 64 per unit, 128 matrix cycles apart)
+    static constexpr int E_RAW_LOAD = 0;                   // raw float4 #k is requested at event k
+    static constexpr int E_RAW_STORE = 22;                 // ... and written to sR at event 22 + k
+    static constexpr int E_XFORM = 32;                     // mid barrier before this event; the transform follows
+    static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 64 && NTILES > 32, "tile must hold 33..64 2x2 tiles");
+    static_assert(ITER_R <= 8 && E_RAW_STORE + ITER_R <= E_XFORM, "raw staging does not fit the schedule");
+    static_assert(LDS_BYTES + 6144 <= 160 * 1024, "LDS tile too large");
+    static_assert(EPI == DCX_EPI_BNRELU || (EPI == DCX_EPI_HEAT && !POOL), "unsupported epilogue");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 sB[];
+    constexpr int TX = C::TX, RW = C::RW, ITER_R = C::ITER_R, LDSF = C::LDS_FLOAT4, CQC = C::CQC, VPLANE = C::VPLANE;
+    constexpr int NQ = C::NQ, DQ = C::DQ, DQB = C::DQB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- work list ------------------------------------------------------------------------------
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int n_ct = a.cout_pad / C::COUT_TILE;
+    int n_eff = a.n;
+    if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
+    const int total = n_eff * n_ct * tiles;
+    int w = blockIdx.x;
+    if (w >= total) return;
+    if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+        a.clk_probe[0] = __builtin_amdgcn_s_memtime();
+        a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    const int gstride = gridDim.x;
+    const int nch = a.cin / DCX_CCH;
+    auto decode = [&](int wi) {
+        DcxItem it;
+        it.tx = wi % a.tiles_x; wi /= a.tiles_x;
+        it.ty = wi % a.tiles_y; wi /= a.tiles_y;
+        it.ct = wi % n_ct;
+        it.n = wi / n_ct;
+        return it;
+    };
+    const int hl = a.hin << a.ups, wl = a.win << a.ups;
+
+    // ---- the lane's 2x2 output tile ---------------------------------------------------------------
+    const int qt = wn * 32 + l31;
+    const bool qok = qt < C::NTILES;
+    const int qty = qt / TX, qtx = qt - qty * TX;
+    const int tile_b = half * 64 + (qok ? qt : 0);        // + (pos * CQC + 2s) * 64  ->  sV index of the B operand
+
+    // ---- operand fetch ---------------------------------------------------------------------------
+    // weights: [pos][cin/4][cout_pad][4]
+    const unsigned w_lane_off = (unsigned)((half * a.cout_pad) + wm * 32 + l31) * 16u;
+    const unsigned w_pos_stride = (unsigned)((a.cin >> 2) * a.cout_pad) * 16u;
+    const unsigned w_s_stride = (unsigned)(2 * a.cout_pad) * 16u;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w_wino2), (short)0, (int)(16u * w_pos_stride), 0x00020000);
+    auto unit_wbase = [&](const DcxItem& it, int c) {
+        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u;
+    };
+    auto load_a = [&](unsigned wbase, int q) {      // q = s * 16 + pos
+        const unsigned soff = wbase + (unsigned)(q & 15) * w_pos_stride + (unsigned)(q >> 4) * w_s_stride;
+        const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane_off, soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto load_b = [&](int buf, int q) {
+        return sB[buf * LDSF + ((q & 15) * CQC + 2 * (q >> 4)) * 64 + tile_b];
+    };
+
+    // ---- staging ----------------------------------------------------------------------------------
+    int r_hy[ITER_R], r_hx[ITER_R];
+    unsigned r_rel[ITER_R];
+#pragma unroll
+    for (int k = 0; k < ITER_R; ++k) {
+        const int idx = tid + k * C::NTHREADS;
+        const int cq = idx / (C::HH * RW);
+        const int hp = idx - cq * (C::HH * RW);
+        r_hy[k] = hp / RW;
+        r_hx[k] = hp - r_hy[k] * RW;
+        const int prow = ((r_hy[k] - a.pad) >> a.ups) + a.pad, pcol = ((r_hx[k] - a.pad) >> a.ups) + a.pad;
+        r_rel[k] = idx < C::RAW ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
+    }
+    float4* sR = sB + 2 * LDSF;
+    // transform piece of this thread: (cq, tile) = (tid / 64, tid % 64); tiles past the end redo the last tile
+    const int x_cq = tid >> 6;
+    const int x_tile = min(tid & 63, C::NTILES - 1);
+    const int x_ty = x_tile / TX, x_tx = x_tile - x_ty * TX;
+    const int x_src = (x_cq * C::HH + 2 * x_ty) * RW + 2 * x_tx;     // raw index of the window's top-left pixel
+    const int x_dst = x_cq * 64 + x_tile;                            // + pos * VPLANE
+    auto unit_rsrc = [&](const DcxItem& it, int c) {
+        const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
+        const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
+                                    + tile_off) * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+    };
+    auto tile_interior = [&](const DcxItem& it) {
+        const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
+        return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + RW <= wl;
+    };
+    auto stage_fetch = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    // float4 a -/+ b as two packed adds (epilogue)
+    auto sub4 = [](const float4& x, const float4& y) {
+        const dcx_f32x2 lo = dcx_pk_sub(dcx_f32x2{x.x, x.y}, dcx_f32x2{y.x, y.y}), hi = dcx_pk_sub(dcx_f32x2{x.z, x.w}, dcx_f32x2{y.z, y.w});
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto add4 = [](const float4& x, const float4& y) {
+        const dcx_f32x2 lo = dcx_pk_add(dcx_f32x2{x.x, x.y}, dcx_f32x2{y.x, y.y}), hi = dcx_pk_add(dcx_f32x2{x.z, x.w}, dcx_f32x2{y.z, y.w});
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    };
+    // Input transform of the thread's (cq, tile) piece as 19 events: state = raw rows r1, r2, one more row (r0, later r3),
+    // the current t[4] and one finished position waiting for its LDS write (issued one event after its adds, so the
+    // write never waits for the vector ALU).
+    //   event 0: read rows 0 and 2 (8 ds_read_b128)      event 1: read row 1      event 6: also read row 3
+    //   event 2 + ms (ms = xi*4 + nu = 0..15): at nu == 0 form t[xi] (8 packed adds), then position ms (2 packed adds)
+    //   event 18: last write
+    float4 xr1[4], xr2[4], xra[4], xt[4], xv;
+    auto xform_read = [&](int which) {
+#pragma unroll
+        for (int cidx = 0; cidx < 4; ++cidx) {
+            if (which == 0) { xra[cidx] = sR[x_src + 0 * RW + cidx]; xr2[cidx] = sR[x_src + 2 * RW + cidx]; }
+            if (which == 1) xr1[cidx] = sR[x_src + 1 * RW + cidx];
+            if (which == 3) xra[cidx] = sR[x_src + 3 * RW + cidx];
+        }
+    };
+    auto xform_event = [&](float4* vbuf, int x) {      // x = 0 .. 18
+        if (x == 0) xform_read(0);
+        else if (x == 1) xform_read(1);
+        else {
+            const int ms = x - 2;
+            if (ms > 0) vbuf[x_dst + (ms - 1) * VPLANE] = xv;      // position ms-1, computed one event ago
+            if (ms < 16) {
+                const int xi = ms >> 2, nu = ms & 3;
+                if (nu == 0) {
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx)
+                        xt[cidx] = xi == 0 ? sub4(xra[cidx], xr2[cidx]) : xi == 1 ? add4(xr1[cidx], xr2[cidx])
+                                 : xi == 2 ? sub4(xr2[cidx], xr1[cidx]) : sub4(xr1[cidx], xra[cidx]);
+                }
+                xv = nu == 0 ? sub4(xt[0], xt[2]) : nu == 1 ? add4(xt[1], xt[2]) : nu == 2 ? sub4(xt[2], xt[1]) : sub4(xt[1], xt[3]);
+                if (ms == 4) xform_read(3);          // row 0 is dead after t[0]; row 3 lands long before ms == 12
+            }
+        }
+    };
+
+    // ---- epilogue constants in LDS: alpha, beta2 (, head weights) ----------------------------------------
+    float4* sP = sB + 2 * LDSF + C::RAW_PAD;
+    const int cq_pad = a.cout_pad >> 2;
+    for (int i = tid; i < cq_pad; i += C::NTHREADS) {
+        sP[i] = reinterpret_cast<const float4*>(a.alpha)[i];
+        sP[cq_pad + i] = reinterpret_cast<const float4*>(a.beta)[i];
+        if (C::EPI == DCX_EPI_HEAT) sP[2 * cq_pad + i] = reinterpret_cast<const float4*>(a.head_w)[i];
+    }
+    const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
+
+    // Accumulators are only ever defined by inline asm with an AGPR constraint: a C++ "acc = 0" makes the loop-carried
+    // value a VGPR-class phi and hipcc then copies all 256 registers AGPR <-> VGPR around every unit.  Clearing = one MFMA
+    // with zero operands and a zero C per accumulator (0*0 + 0, exact).
+    dcx_f32x16 acc[16];
+    auto clear_acc = [&]() {
+        const float fz = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)   // s_nop 1: `fz` may have been written by the VALU instruction just before (VALU -> MFMA
+                                       // operand needs 2 wait states; hipcc pads nothing inside or around an asm statement)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %1, 0" : "=a"(acc[p]) : "v"(fz));
+    };
+    clear_acc();
+
+    // ---- prologue: first unit staged synchronously ---------------------------------------------
+    DcxItem cur = decode(w);
+    int c = 0;
+    float4 a_c[DQ];
+    {
+        const unsigned wb = unit_wbase(cur, 0);
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) a_c[d] = load_a(wb, d);
+        const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(cur, 0);
+        const int sy0 = cur.ty * C::TH - a.pad, sx0 = cur.tx * C::TW - a.pad;
+#pragma unroll
+        for (int k = 0; k < ITER_R; ++k) {
+            const int ly = sy0 + r_hy[k], lx = sx0 + r_hx[k];
+            const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+            sR[tid + k * C::NTHREADS] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 19; ++x) xform_event(sB, x);
+    }
+
+    for (int u = 0;; ++u) {
+        DcxItem nxt = cur;
+        int cn = c + 1;
+        bool has_next = true;
+        if (cn == nch) {
+            if (w + gstride < total) { nxt = decode(w + gstride); cn = 0; }
+            else { has_next = false; cn = c; }
+        }
+        const int buf = u & 1;
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[4 + 3 * u] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[5 + 3 * u] = __builtin_amdgcn_s_memtime();
+
+        const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
+        const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
+        const unsigned wb_cur = unit_wbase(cur, c);
+        const unsigned wb_nxt = unit_wbase(nxt, cn);
+        float4 aq[NQ + DQ], bq[NQ];
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) aq[d] = a_c[d];
+#pragma unroll
+        for (int d = 0; d < DQB; ++d) bq[d] = load_b(buf, d);
+        float4* vnext = sB + (buf ^ 1) * LDSF;
+        float4 rv[ITER_R];
+        const bool n_interior = tile_interior(nxt);
+        unsigned roff[ITER_R];
+#pragma unroll
+        for (int k = 0; k < ITER_R; ++k) roff[k] = r_rel[k];
+        if (!n_interior) {
+#pragma unroll
+            for (int k = 0; k < ITER_R; ++k) {
+                const int ly = nsy0 + r_hy[k], lx = nsx0 + r_hx[k];
+                roff[k] = ((unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl) ? r_rel[k] : 0x80000000u;
+            }
+        }
+        // Positions are processed in pairs (qa, qb = qa + 1): 8 MFMAs alternating between the two accumulators, one slot
+        // (= one staging event) before each MFMA pair; slots 0 / 1 also fetch A, B of qa + DQ / qb + DQ.
+#pragma unroll
+        for (int qa = 0; qa < NQ; qa += 2) {
+            const int qb = qa + 1;
+            if (qa * 2 == C::E_XFORM) __syncthreads();      // the raw tile of the next unit is complete in sR
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (slot < 2) {
+                    const int q = qa + slot + DQ, qb2 = qa + slot + DQB;
+                    if (q < NQ) aq[q] = load_a(wb_cur, q);
+                    else aq[q] = load_a(wb_nxt, q - NQ);
+                    if (qb2 < NQ) bq[qb2] = load_b(buf, qb2);
+                }
+                {
+                    const int e = qa * 2 + slot;          // staging event 0 .. 63
+                    if (e >= C::E_RAW_LOAD && e < C::E_RAW_LOAD + ITER_R) rv[e - C::E_RAW_LOAD] = stage_fetch(rs_n, roff[e - C::E_RAW_LOAD]);
+                    if (e >= C::E_RAW_STORE && e < C::E_RAW_STORE + ITER_R) sR[tid + (e - C::E_RAW_STORE) * C::NTHREADS] = rv[e - C::E_RAW_STORE];
+                    if (e >= C::E_XFORM && e < C::E_XFORM + 19) xform_event(vnext, e - C::E_XFORM);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // MFMAs of this slot: register j = slot of qa, then of qb
+                {
+                    const int pa = qa & 15, pb = qb & 15;
+                    const float4 aa = aq[qa], ba = bq[qa], ab = aq[qb], bb = bq[qb];
+                    const float av0 = slot == 0 ? aa.x : slot == 1 ? aa.y : slot == 2 ? aa.z : aa.w;
+                    const float bv0 = slot == 0 ? ba.x : slot == 1 ? ba.y : slot == 2 ? ba.z : ba.w;
+                    const float av1 = slot == 0 ? ab.x : slot == 1 ? ab.y : slot == 2 ? ab.z : ab.w;
+                    const float bv1 = slot == 0 ? bb.x : slot == 1 ? bb.y : slot == 2 ? bb.z : bb.w;
+                    // inline asm pins the register classes: accumulators in AGPRs, operands in VGPRs.  With the builtin, hipcc
+                    // treats the 512 registers as one pool under this kernel's pressure and shuffles accumulators through
+                    // VGPRs and scratch inside the loop.  (Consecutive MFMAs alternate between two accumulators.)
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pa]) : "v"(av0), "v"(bv0));
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pb]) : "v"(av1), "v"(bv1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) a_c[d] = aq[NQ + d];
+
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[6 + 3 * u] = __builtin_amdgcn_s_memtime();
+        if (c == nch - 1) {
+            // ---- epilogue: 2-D output transform, BN, ReLU (, pool | head), store -----------------------
+            // (the MFMAs are inline asm, so the compiler does not know the MFMA -> v_accvgpr_read distance; the code between
+            //  the last MFMA and the first read is far longer than the 18 wait states required, the nops make it explicit)
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+            // re-define the accumulators here (empty asm, AGPR class): the AGPR -> VGPR copies the transform below needs are
+            // then created inside this block instead of being hoisted into the k-loop (where hipcc otherwise puts them)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
+            const int oy0 = cur.ty * C::TH + 2 * qty, ox0 = cur.tx * C::TW + 2 * qtx;
+            const unsigned plane = (unsigned)(hs * ws);
+            const int cq_w0 = (cur.ct * C::COUT_TILE >> 2) + wm * 8;
+            char* obase = reinterpret_cast<char*>(a.out)
+                        + ((size_t)cur.n * a.out_cq_total + a.out_cq_off + cq_w0) * (size_t)plane * 16;
+            const bool okr0 = qok && oy0 < a.ho, okr1 = qok && oy0 + 1 < a.ho;
+            const bool okc0 = ox0 < a.wo, okc1 = ox0 + 1 < a.wo;
+            const unsigned lane_off = C::POOL ? ((unsigned)half * plane + (unsigned)((oy0 >> 1) * ws + (ox0 >> 1))) * 16u
+                                              : ((unsigned)half * plane + (unsigned)(oy0 * ws + ox0)) * 16u;
+            float hsum[4] = {0.f, 0.f, 0.f, 0.f};
+            // Output transform, position-outer: y[k = 2i+j] = sum over positions p = xi*4 + nu (ascending) of
+            // AT[i][xi] * AT[j][nu] * m[p], AT = [[1,1,1,0],[0,1,-1,-1]] -- the first non-zero term initialises, the others
+            // are added or subtracted in order (this order is part of the kernel's numerical specification).  One
+            // accumulator (16 registers) is copied out of the AGPRs at a time; the separable form needs 24 instead of 32
+            // float4 operations per cout quad but all 256 accumulator registers at once, which spills.
+#pragma unroll
+            for (int gh = 0; gh < 2; ++gh) {     // two cout quads at a time (32 + 16 live registers)
+            float4 yq[4][2];     // [k][g - 2*gh]
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int xi = p >> 2, nu = p & 3;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int g = 2 * gh + g2;
+                    const float4 m = make_float4(acc[p][4 * g + 0], acc[p][4 * g + 1], acc[p][4 * g + 2], acc[p][4 * g + 3]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = k >> 1, jj = k & 1;
+                        const int ci = i == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : xi == 1 ? 1 : -1);
+                        const int cj = jj == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : nu == 1 ? 1 : -1);
+                        const int cf = ci * cj;
+                        const int first = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 4 : 5;
+                        if (cf != 0) {
+                            if (p == first) yq[k][g2] = m;
+                            else yq[k][g2] = cf > 0 ? add4(yq[k][g2], m) : sub4(yq[k][g2], m);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int g = 2 * gh + g2;
+                const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 8 + 2 * g + half;
+                const float4 al = sP[cq], be = sP[cq_pad + cq];
+                float4 y[4];     // y[2*i + j]
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = dcx_fma4(yq[k][g2], al, be);
+                char* dst = obase + (size_t)((unsigned)(2 * g) * plane * 16u) + lane_off;
+                if (C::POOL) {
+                    float4 v;
+                    v.x = dcx_vmax(dcx_vmax(dcx_vmax(y[0].x, y[1].x), dcx_vmax(y[2].x, y[3].x)), 0.f);
+                    v.y = dcx_vmax(dcx_vmax(dcx_vmax(y[0].y, y[1].y), dcx_vmax(y[2].y, y[3].y)), 0.f);
+                    v.z = dcx_vmax(dcx_vmax(dcx_vmax(y[0].z, y[1].z), dcx_vmax(y[2].z, y[3].z)), 0.f);
+                    v.w = dcx_vmax(dcx_vmax(dcx_vmax(y[0].w, y[1].w), dcx_vmax(y[2].w, y[3].w)), 0.f);
+                    if (okr0 && okc0 && cq < a.cout_quads) *reinterpret_cast<float4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        y[k].x = dcx_vmax(y[k].x, 0.f); y[k].y = dcx_vmax(y[k].y, 0.f);
+                        y[k].z = dcx_vmax(y[k].z, 0.f); y[k].w = dcx_vmax(y[k].w, 0.f);
+                    }
+                    if (C::EPI == DCX_EPI_HEAT) {
+                        const float4 hw = sP[2 * cq_pad + cq];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float h = hsum[k];
+                            h = fmaf(y[k].x, hw.x, h); h = fmaf(y[k].y, hw.y, h);
+                            h = fmaf(y[k].z, hw.z, h); h = fmaf(y[k].w, hw.w, h);
+                            hsum[k] = h;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (cq < a.cout_quads) {
+                        if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = y[0];
+                        if (okr0 && okc1) *reinterpret_cast<float4*>(dst + 16) = y[1];
+                        if (okr1 && okc0) *reinterpret_cast<float4*>(dst + (size_t)ws * 16) = y[2];
+                        if (okr1 && okc1) *reinterpret_cast<float4*>(dst + (size_t)ws * 16 + 16) = y[3];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);    // keep the second half's AGPR reads out of the first half (register pressure)
+            }   // gh
+            if (C::EPI == DCX_EPI_HEAT) {
+                // logit = ((h[wm0,half0] + h[wm0,half1]) + (h[wm1,half0] + h[wm1,half1])) + bias, as in the 1-D kernel
+                float t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = hsum[k] + __shfl_xor(hsum[k], 32);
+                __syncthreads();
+                float* scr = reinterpret_cast<float*>(sB + buf * LDSF);
+                if (wm == 1 && half == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) scr[(wn * 32 + l31) * 4 + k] = t[k];
+                }
+                __syncthreads();
+                float best = -INFINITY;
+                int besti = 0x7fffffff;
+                if (wm == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lg = (t[k] + scr[(wn * 32 + l31) * 4 + k]) + a.head_b;
+                        const int sy = oy0 + (k >> 1), sx = ox0 + (k & 1);
+                        const bool ok = qok && sy < a.ho && sx < a.wo;
+                        if (ok) {
+                            const int idx = sy * a.wo + sx;
+                            if (a.heat != nullptr && half == 0) a.heat[((size_t)cur.n * a.ho + sy) * a.wo + sx] = lg;
+                            if (lg > best || (lg == best && idx < besti)) { best = lg; besti = idx; }
+                        }
+                    }
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        const float ov = __shfl_xor(best, off);
+                        const int oi = __shfl_xor(besti, off);
+                        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                    }
+                }
+                float* red_v = scr + 512;
+                int* red_i = reinterpret_cast<int*>(scr) + 512 + 16;
+                if (wm == 0 && lane == 0) { red_v[wn] = best; red_i[wn] = besti; }
+                __syncthreads();
+                if (tid == 0) {
+                    const float ov = red_v[1];
+                    const int oi = red_i[1];
+                    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                    a.part_val[(size_t)cur.n * tiles + cur.ty * a.tiles_x + cur.tx] = best;
+                    a.part_idx[(size_t)cur.n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
+                }
+            }
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // the epilogue's last v_accvgpr_read is far behind; explicit anyway
+            clear_acc();
+        }
+
+        if (!has_next) {
+            if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+                a.clk_probe[2] = __builtin_amdgcn_s_memtime();
+                a.clk_probe[3] = __builtin_amdgcn_s_memrealtime();
+            }
+            break;
+        }
+        if (cn == 0) w += gstride;
+        cur = nxt;
+        c = cn;
+    }
+}
+
+template <class C>
+static int dcx_conv_wino2_launch_cfg(DcxConvArgs a, hipStream_t stream) {
+    a.tiles_x = (a.wo + C::TW - 1) / C::TW;
+    a.tiles_y = (a.ho + C::TH - 1) / C::TH;
+    if (a.w_wino2 == nullptr || a.alpha == nullptr || a.beta == nullptr) return DCX_E_ARG;
+    if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0) return DCX_E_SHAPE;
+    if (C::EPI == DCX_EPI_HEAT && (a.head_w == nullptr || a.part_val == nullptr || a.part_idx == nullptr)) return DCX_E_ARG;
+    if (C::EPI != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
+    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
+    if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
+    const long resident = (long)dcx_device_cu_count();      // one workgroup per CU
+    const long blocks = items < resident ? items : resident;
+    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 12;
+    if (lds > 160 * 1024) return DCX_E_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcx_conv_wino2_kernel<C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dcx_conv_wino2_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), lds, stream, a);
+    return (int)hipGetLastError();
+}

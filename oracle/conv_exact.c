@@ -113,3 +113,82 @@ void dcx_oracle_conv_wino_exact(const float* x, int n, int cin, int h, int w, co
                     if (x0 + 1 < wo) row[x0 + 1] = fmaxf(fmaf(o1, alpha[co], b2), 0.0f);
                 }
 }
+
+/* Same layer through the 2-D Winograd F(2x2,3x3) kernel (deepcharuco_amd/csrc/dcx_conv_wino2.h), in ITS exact fp32 order:
+ *   per 2x2 output tile (rows 2ty, 2ty+1; columns 2tx, 2tx+1), channel: d[r][c] = in[2ty-pad+r][2tx-pad+c], r, c = 0..3
+ *     rows     t0 = d[0]-d[2]  t1 = d[1]+d[2]  t2 = d[2]-d[1]  t3 = d[1]-d[3]          (per column c)
+ *     columns  v[xi][0] = t[xi][0]-t[xi][2]  v1 = t1+t2  v2 = t2-t1  v3 = t1-t3
+ *     weights  h[xi][kx] over ky: h0 = g0, h1 = ((g0+g1)+g2)*0.5f, h2 = ((g0-g1)+g2)*0.5f, h3 = g2; then the same over kx
+ *   m[xi][nu] = 0;  for chunk c0 / s / j / k:  m = fmaf(u[ci], v[ci], m),  ci = c0 + 8s + 4k + j
+ *   y[i][j] = sum over (xi, nu), xi-major ascending, of AT[i][xi]*AT[j][nu]*m[xi][nu], AT = [[1,1,1,0],[0,1,-1,-1]]
+ *             (sequential adds / subtracts, the first non-zero term initialises)
+ *   out = max(fmaf(y, alpha, fmaf(bias, alpha, beta)), 0) */
+void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                                 const float* alpha, const float* beta, int cout, int pad, float* y) {
+    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
+    const int nty = (ho + 1) / 2, ntx = (wo + 1) / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < n; ++b)
+        for (int co = 0; co < cout; ++co)
+            for (int ty = 0; ty < nty; ++ty)
+                for (int tx = 0; tx < ntx; ++tx) {
+                    float m[4][4] = {{0.0f}};
+                    for (int c0 = 0; c0 < cin; c0 += 16)
+                        for (int s = 0; s < 2; ++s)
+                            for (int j = 0; j < 4; ++j)
+                                for (int k = 0; k < 2; ++k) {
+                                    const int ci = c0 + 8 * s + 4 * k + j;
+                                    float d[4][4], t[4][4], v[4][4], hh[4][3], u[4][4];
+                                    for (int r = 0; r < 4; ++r)
+                                        for (int c = 0; c < 4; ++c) {
+                                            const int iy = 2 * ty - pad + r, ix = 2 * tx - pad + c;
+                                            const int inb = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                                            d[r][c] = inb ? x[(((size_t)b * cin + ci) * h + iy) * w + ix] : 0.0f;
+                                        }
+                                    for (int c = 0; c < 4; ++c) {
+                                        t[0][c] = d[0][c] - d[2][c]; t[1][c] = d[1][c] + d[2][c];
+                                        t[2][c] = d[2][c] - d[1][c]; t[3][c] = d[1][c] - d[3][c];
+                                    }
+                                    for (int xi = 0; xi < 4; ++xi) {
+                                        v[xi][0] = t[xi][0] - t[xi][2]; v[xi][1] = t[xi][1] + t[xi][2];
+                                        v[xi][2] = t[xi][2] - t[xi][1]; v[xi][3] = t[xi][1] - t[xi][3];
+                                    }
+                                    const float* g = wt + ((size_t)co * cin + ci) * 9;
+                                    for (int kx = 0; kx < 3; ++kx) {
+                                        const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+                                        hh[0][kx] = g0; hh[1][kx] = ((g0 + g1) + g2) * 0.5f;
+                                        hh[2][kx] = ((g0 - g1) + g2) * 0.5f; hh[3][kx] = g2;
+                                    }
+                                    for (int xi = 0; xi < 4; ++xi) {
+                                        u[xi][0] = hh[xi][0]; u[xi][1] = ((hh[xi][0] + hh[xi][1]) + hh[xi][2]) * 0.5f;
+                                        u[xi][2] = ((hh[xi][0] - hh[xi][1]) + hh[xi][2]) * 0.5f; u[xi][3] = hh[xi][2];
+                                    }
+                                    for (int xi = 0; xi < 4; ++xi)
+                                        for (int nu = 0; nu < 4; ++nu) m[xi][nu] = fmaf(u[xi][nu], v[xi][nu], m[xi][nu]);
+                                }
+                    /* output transform, position-outer: o[i][j] = sum over xi, nu (xi-major, ascending) of
+                     * AT[i][xi]*AT[j][nu]*m[xi][nu], AT = [[1,1,1,0],[0,1,-1,-1]]; the first non-zero term initialises */
+                    static const int AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+                    float o[2][2];
+                    for (int i = 0; i < 2; ++i)
+                        for (int jj = 0; jj < 2; ++jj) {
+                            int started = 0;
+                            float acc2 = 0.0f;
+                            for (int xi = 0; xi < 4; ++xi)
+                                for (int nu = 0; nu < 4; ++nu) {
+                                    const int cf = AT[i][xi] * AT[jj][nu];
+                                    if (cf == 0) continue;
+                                    if (!started) { acc2 = m[xi][nu]; started = 1; }   /* the first coefficient is always +1 */
+                                    else acc2 = cf > 0 ? acc2 + m[xi][nu] : acc2 - m[xi][nu];
+                                }
+                            o[i][jj] = acc2;
+                        }
+                    const float b2 = fmaf(bias[co], alpha[co], beta[co]);
+                    for (int i = 0; i < 2; ++i)
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int oy = 2 * ty + i, ox = 2 * tx + jj;
+                            if (oy < ho && ox < wo)
+                                y[(((size_t)b * cout + co) * ho + oy) * wo + ox] = fmaxf(fmaf(o[i][jj], alpha[co], b2), 0.0f);
+                        }
+                }
+}

@@ -26,7 +26,8 @@ def lib():
 
 def conv_exact(x, wt, bias, bn=None, pad=1, ups=False, pool=False, wino=False):
     """x NCHW float32; bn = (gamma, beta, mean, var) or None (raw).  Returns NCHW float32.
-    wino=True: the summation order of the 1-D Winograd F(2,3) kernel (3x3 + BN layers only)."""
+    wino=True: the summation order of the 1-D Winograd F(2,3) kernel, wino=2: of the 2-D F(2x2,3x3) kernel
+    (3x3 + BN layers only)."""
     x = np.ascontiguousarray(x, np.float32)
     if ups:
         x = np.ascontiguousarray(x.repeat(2, axis=2).repeat(2, axis=3))
@@ -42,9 +43,10 @@ def conv_exact(x, wt, bias, bn=None, pad=1, ups=False, pool=False, wino=False):
         g, be, mu, var = [np.ascontiguousarray(t, np.float32) for t in bn]
         alpha, beta = np.empty(cout, np.float32), np.empty(cout, np.float32)
         lib().dcx_oracle_fold_bn(p(g), p(be), p(mu), p(var), cout, p(alpha), p(beta))
-    if wino:
+    if wino:     # True / 1: 1-D F(2,3) along x;  2: 2-D F(2x2,3x3)
         assert bn is not None and ks == 3 and cin % 16 == 0
-        lib().dcx_oracle_conv_wino_exact(p(x), n, cin, h, w, p(wt), p(bias), p(alpha), p(beta), cout, pad, p(y))
+        fn = lib().dcx_oracle_conv_wino2_exact if wino == 2 else lib().dcx_oracle_conv_wino_exact
+        fn(p(x), n, cin, h, w, p(wt), p(bias), p(alpha), p(beta), cout, pad, p(y))
     else:
         lib().dcx_oracle_conv_exact(p(x), n, cin, h, w, p(wt), p(bias), p(alpha) if bn is not None else None,
                                     p(beta) if bn is not None else None, cout, ks, pad, p(y))

@@ -186,7 +186,8 @@ def test_conv_layer_bit_exact_vs_c_restatement(dev, case):
     ho, wo = (h << ups) + 2 * pad - (ks - 1), (w << ups) + 2 * pad - (ks - 1)
     picked = _lib.lib().dcx_conv_pick_name(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1).decode()
     ref = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
-                     pad=pad, ups=bool(ups), pool=bool(pool), wino="wino" in picked)   # each kernel has its own order
+                     pad=pad, ups=bool(ups), pool=bool(pool),
+                     wino=2 if "wino2" in picked else 1 if "wino" in picked else 0)   # each kernel has its own order
     nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     _report(f"conv_layer_bitexact/{name}", dict(kernel=picked[picked.find("dcx_conv_") + 9:], mismatching_elements=nbad,
                                                 max_abs=float(np.abs(got - ref).max())))
@@ -228,7 +229,7 @@ def test_every_conv_instantiation_bit_exact(dev, monkeypatch):
             if L.dcx_conv_pick_name(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1).decode() != cfg:
                 continue      # this instantiation cannot run this layer (kernel size / pooling / cout tile)
             got = _conv_layer(x.to(dev), wt, b, bn, pad, ups, pool, ks).cpu().numpy()
-            wino = "wino" in cfg
+            wino = 2 if "wino2" in cfg else 1 if "wino" in cfg else 0
             if wino not in refs:
                 refs[wino] = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
                                         pad=pad, ups=bool(ups), pool=bool(pool), wino=wino)

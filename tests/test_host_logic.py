@@ -125,17 +125,19 @@ def test_shard_range_partition():
 
 def test_tile_cost_model_choices():
     """The host-side tile selection (csrc/dcx_conv_mfma.hip: pick) is a cost model; these are the choices the
-    design relies on: the 1-D Winograd kernels when a launch has plenty of work, the 64x64 S tile of the direct kernel
-    when it has few items, the direct kernels for 1x1 and the fused RefineNet head."""
+    design relies on: the 2-D Winograd kernel (one workgroup per CU) when a launch has plenty of work, the 1-D Winograd
+    kernel for medium launches and the fused RefineNet head, the 64x64 S tile of the direct kernel when a launch has few
+    items, the direct kernel for 1x1."""
     from deepcharuco_amd import _lib
     L = _lib.lib()
     name = lambda *a: L.dcx_conv_pick_name(*a).decode()
-    assert name(32, 64, 240, 320, 64, 3, 1, 0) == "dcx_conv_wino_kernel<DcxWinoCfg<2,2,4,32,1>>"     # conv1b, bs=32
-    assert name(128, 64, 480, 640, 64, 3, 1, 0) == "dcx_conv_wino_kernel<DcxWinoCfg<2,2,4,32,1>>"    # conv1b, cfg3
-    assert "DcxWinoCfg<2,2,4,32,0>" in name(32, 64, 120, 160, 64, 3, 0, 0)               # conv2a
-    assert "DcxWinoCfg<2,2,8,16,0>" in name(32, 128, 30, 40, 128, 3, 0, 0)               # conv4a bs=32 (30 rows: 8x16 tiles)
-    assert "<2,2,1,1,8,8,3,0,DCX_EPI_BNRELU>" in name(1, 128, 30, 40, 128, 3, 0, 0)      # bs=1: few items -> S tile
-    assert "DcxWinoCfg<2,2,4,32,1>" in name(1, 64, 240, 320, 64, 3, 1, 0)                # conv1b bs=1
+    assert name(32, 64, 240, 320, 64, 3, 1, 0) == "dcx_conv_wino2_kernel<DcxWino2Cfg<16,16,1>>"      # conv1b, bs=32: 2-D Winograd
+    assert name(128, 64, 480, 640, 64, 3, 1, 0) == "dcx_conv_wino2_kernel<DcxWino2Cfg<16,16,1>>"     # conv1b, cfg3
+    assert "DcxWino2Cfg<16,16,0>" in name(32, 64, 120, 160, 64, 3, 0, 0)                 # conv2a
+    assert "DcxWino2Cfg<6,40,0>" in name(32, 128, 30, 40, 512, 3, 0, 0)                  # fused heads' 3x3 on the 30x40 map
+    assert "<2,2,1,1,8,8,3,0,DCX_EPI_BNRELU>" in name(1, 128, 30, 40, 128, 3, 0, 0)      # bs=1: few items -> S tile (direct)
+    assert "DcxWinoCfg<2,2,4,32,1>" in name(1, 64, 240, 320, 64, 3, 1, 0)                # conv1b bs=1: 1-D Winograd (2 workgroups/CU)
+    assert "DcxWinoCfg<2,2,4,32,0,DCX_EPI_HEAT>" in name(512, 64, 64, 64, 64, 3, 0, 2)   # RefineNet head: 1-D Winograd
     assert "DCX_EPI_HEAT" in name(512, 64, 64, 64, 64, 3, 0, 2)
     assert "<1,4,2,2,1,256,1,0,DCX_EPI_RAW>" in name(32, 256, 1, 1200, 65, 1, 0, 1)
     assert name(32, 64, 30, 40, 64, 3, 0, 1) == ""                              # no raw 3x3 instantiation
@@ -166,8 +168,8 @@ def test_c_restatement_agrees_with_torch_fp32():
             ref = F.relu(F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5))
         if pool:
             ref = F.max_pool2d(ref, 2, 2)
-        # the direct order, and for 3x3 + BN layers with cin % 16 == 0 also the 1-D Winograd F(2,3) order
-        for wino in ([False, True] if (ks == 3 and has_bn and cin % 16 == 0) else [False]):
+        # the direct order, and for 3x3 + BN layers with cin % 16 == 0 also the 1-D F(2,3) and 2-D F(2x2,3x3) Winograd orders
+        for wino in ([0, 1, 2] if (ks == 3 and has_bn and cin % 16 == 0) else [0]):
             got = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
                              pad=pad, ups=ups, pool=pool, wino=wino)
             assert got.shape == tuple(ref.shape)

@@ -3,11 +3,11 @@ usage: python tools/isa_mix.py [substring of the mangled kernel name ...]"""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(tempfile.gettempdir(), "dcx_conv.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-mllvm", "-pragma-unroll-threshold=200000", "-S",
                 os.path.join(ROOT, "deepcharuco_amd/csrc/dcx_conv_mfma.hip"), "-o", out], check=True, capture_output=True)
 s = open(out).read()
 pats = sys.argv[1:] or ["wino"]
-for m in re.finditer(r"^(_Z20dcx_conv_\w+):[^\n]*\n", s, re.M):
+for m in re.finditer(r"^(_Z2[0-9]dcx_conv_\w+):[^\n]*\n", s, re.M):
     sym = m.group(1)
     if not any(p in sym for p in pats):
         continue

@@ -22,6 +22,12 @@ def per_kernel(path, counter):
 
 
 def lib_name(rocprof_name):
+    m = re.search(r"DcxWino2Cfg<([^>]*)>", rocprof_name)
+    if m:   # <TH, TW, POOL, EPI>
+        f = [x.strip() for x in m.group(1).split(",")]
+        f[2] = "1" if f[2] == "true" else "0"
+        epi = f[3] if len(f) > 3 else "0"
+        return "dcx_conv_wino2_kernel<DcxWino2Cfg<" + ",".join(f[:3]) + (",DCX_EPI_HEAT" if epi == "2" else "") + ">>"
     m = re.search(r"DcxWinoCfg<([^>]*)>", rocprof_name)
     if m:   # <WM, WN, TH, TW, POOL, EPI> -> the name dcx_profile_kernel_name() reports
         f = [x.strip() for x in m.group(1).split(",")]
