@@ -85,7 +85,7 @@ const CfgEntry kCfgs[] = {
     DCX_W2CFG(6, 40, 0),      // 30x40 maps: 3 x 20 tiles
     DCX_W2CFG(16, 16, 1),
     DCX_W2CFG(8, 32, 1),
-    // (the 2-D head variant works -- DCX_W2CFG_HEAT(16, 16) -- but its epilogue spills and it measured slower than the 1-D head)
+    DCX_W2CFG_HEAT(16, 16),
 };
 
 int dcx_wino2_enabled() {   // on by default; DCX_WINO2=0 keeps the 1-D Winograd / direct kernels (A/B runs)

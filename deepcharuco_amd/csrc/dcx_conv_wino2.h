@@ -309,6 +309,13 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
                     // inline asm pins the register classes: accumulators in AGPRs, operands in VGPRs.  With the builtin, hipcc
                     // treats the 512 registers as one pool under this kernel's pressure and shuffles accumulators through
                     // VGPRs and scratch inside the loop.  (Consecutive MFMAs alternate between two accumulators.)
+                    // Hazards (hipcc pads nothing around an asm statement): the operands come straight from loads, which hipcc
+                    // waits for; the only VALU-written candidates are the weight registers carried over from the previous
+                    // unit (possible v_mov copies just before the loop) -> 2 wait states ahead of the unit's first MFMAs.
+                    // C is always the previous D of the same accumulator (accumulate chain: no wait states).
+                    // (A C = 0 variant of the first k-step, chosen by one branch per unit, was tried to save the per-item
+                    //  clear: hipcc reconciles the two variants by moving accumulators through VGPRs and scratch -- 535 spills.)
+                    if (qa == 0 && slot == 0) asm volatile("s_nop 1");
                     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pa]) : "v"(av0), "v"(bv0));
                     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pb]) : "v"(av1), "v"(bv1));
                 }
@@ -392,6 +399,8 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
                         y[k].z = dcx_vmax(y[k].z, 0.f); y[k].w = dcx_vmax(y[k].w, 0.f);
                     }
                     if (C::EPI == DCX_EPI_HEAT) {
+                        if (cq >= a.cout_quads) continue;   // padded couts contribute 0; the (uniform) branch also ends the basic
+                                                            // block, which keeps hipcc from merging the two halves' register use
                         const float4 hw = sP[2 * cq_pad + cq];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {

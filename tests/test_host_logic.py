@@ -176,6 +176,33 @@ def test_c_restatement_agrees_with_torch_fp32():
             assert np.abs(got - ref.numpy()).max() <= 2e-5, (wino, cin, cout)
 
 
+def test_conv_kernels_do_not_spill():
+    """The Winograd kernels are written around hipcc's register allocation (accumulators pinned to AGPRs with inline asm,
+    one basic block per unit): a change that makes hipcc shuffle accumulators or spill shows up as a large slowdown only
+    on the GPU.  This guards the budget at build time: no VGPR spills in any MFMA kernel of the dispatch table, and no
+    scratch / accumulator moves inside the unit loops of the Winograd kernels."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(REPO, "deepcharuco_amd", "csrc", "dcx_conv_mfma.hip")
+    out = os.path.join(tempfile.gettempdir(), "dcx_conv_budget.s")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-mllvm",
+                    "-pragma-unroll-threshold=200000", "-S", src, "-o", out], check=True, capture_output=True)
+    asm = open(out).read()
+    spills = dict(re.findall(r"\.name:\s+(_Z2\ddcx_conv_\w+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", asm))
+    assert len(spills) >= 30
+    default_off = ("ILi1ELi4ELi2ELi4E",)      # the opt-in 64x512 "big" direct tiles (DCX_BIG_TILES=1)
+    bad = {k: v for k, v in spills.items() if int(v) != 0 and not any(t in k for t in default_off)}
+    assert not bad, f"kernels with VGPR spills: {bad}"
+    for m in re.finditer(r"^(_Z2\ddcx_conv_wino2?_kernel\w+):[^\n]*\n", asm, re.M):
+        body = asm[m.end():asm.index(".Lfunc_end", m.end())]
+        blocks = re.split(r"\n\.LBB[0-9_]+:", body)
+        loops = [b for b in blocks if b.count("v_mfma") >= 64]
+        assert loops, m.group(1)
+        for b in loops:
+            assert "scratch_" not in b and "v_accvgpr" not in b, f"{m.group(1)}: spill or accumulator move inside the unit loop"
+
+
 def test_missing_native_library_fails_loudly(monkeypatch, tmp_path):
     """No fallback: without libdeepcharuco_amd.so every entry into the library raises (nothing is computed on the
     CPU or through stock PyTorch operators instead)."""
