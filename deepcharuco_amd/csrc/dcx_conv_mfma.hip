@@ -83,6 +83,7 @@ const CfgEntry kCfgs[] = {
     DCX_W2CFG(16, 16, 0),
     DCX_W2CFG(8, 32, 0),
     DCX_W2CFG(6, 40, 0),      // 30x40 maps: 3 x 20 tiles
+    DCX_W2CFG(24, 10, 0),     // RefineNet's 24 / 22 / 20-pixel maps: 12 x 5 tiles
     DCX_W2CFG(16, 16, 1),
     DCX_W2CFG(8, 32, 1),
     DCX_W2CFG_HEAT(16, 16),
