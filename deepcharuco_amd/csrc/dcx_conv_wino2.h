@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
             // float4 operations per cout quad but all 256 accumulator registers at once, which spills.
 #pragma unroll
             for (int gh = 0; gh < 2; ++gh) {     // two cout quads at a time (32 + 16 live registers)
+            if (gh == 1) {       // again: keeps hipcc from copying whole 16-register accumulators for the second half
+#pragma unroll
+                for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
+            }
             float4 yq[4][2];     // [k][g - 2*gh]
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
