@@ -125,9 +125,9 @@ def test_shard_range_partition():
 
 def test_tile_cost_model_choices():
     """The host-side tile selection (csrc/dcx_conv_mfma.hip: pick) is a cost model; these are the choices the
-    design relies on: the 2-D Winograd kernel (one workgroup per CU) when a launch has plenty of work, the 1-D Winograd
-    kernel for medium launches and the fused RefineNet head, the 64x64 S tile of the direct kernel when a launch has few
-    items, the direct kernel for 1x1."""
+    design relies on: the 2-D Winograd kernel (one workgroup per CU) when a launch has plenty of work (incl. the fused
+    RefineNet head), the 1-D Winograd kernel for medium launches, the 64x64 S tile of the direct kernel when a launch has
+    few items, the direct kernel for 1x1."""
     from deepcharuco_amd import _lib
     L = _lib.lib()
     name = lambda *a: L.dcx_conv_pick_name(*a).decode()
@@ -137,7 +137,7 @@ def test_tile_cost_model_choices():
     assert "DcxWino2Cfg<6,40,0>" in name(32, 128, 30, 40, 512, 3, 0, 0)                  # fused heads' 3x3 on the 30x40 map
     assert "<2,2,1,1,8,8,3,0,DCX_EPI_BNRELU>" in name(1, 128, 30, 40, 128, 3, 0, 0)      # bs=1: few items -> S tile (direct)
     assert "DcxWinoCfg<2,2,4,32,1>" in name(1, 64, 240, 320, 64, 3, 1, 0)                # conv1b bs=1: 1-D Winograd (2 workgroups/CU)
-    assert "DcxWinoCfg<2,2,4,32,0,DCX_EPI_HEAT>" in name(512, 64, 64, 64, 64, 3, 0, 2)   # RefineNet head: 1-D Winograd
+    assert "DcxWino2Cfg<16,16,0,DCX_EPI_HEAT>" in name(512, 64, 64, 64, 64, 3, 0, 2)     # RefineNet head: 2-D Winograd
     assert "DCX_EPI_HEAT" in name(512, 64, 64, 64, 64, 3, 0, 2)
     assert "<1,4,2,2,1,256,1,0,DCX_EPI_RAW>" in name(32, 256, 1, 1200, 65, 1, 0, 1)
     assert name(32, 64, 30, 40, 64, 3, 0, 1) == ""                              # no raw 3x3 instantiation
