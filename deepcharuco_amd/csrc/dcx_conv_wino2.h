@@ -162,12 +162,12 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
         const dcx_f32x2 lo = dcx_pk_add(dcx_f32x2{x.x, x.y}, dcx_f32x2{y.x, y.y}), hi = dcx_pk_add(dcx_f32x2{x.z, x.w}, dcx_f32x2{y.z, y.w});
         return make_float4(lo.x, lo.y, hi.x, hi.y);
     };
-    // Input transform of the thread's (cq, tile) piece as 19 events: state = raw rows r1, r2, one more row (r0, later r3),
+    // Input transform of the thread's (cq, tile) piece as 21 events: state = raw rows r1, r2, one more row (r0, later r3),
     // the current t[4] and one finished position waiting for its LDS write (issued one event after its adds, so the
     // write never waits for the vector ALU).
-    //   event 0: read rows 0 and 2 (8 ds_read_b128)      event 1: read row 1      event 6: also read row 3
-    //   event 2 + ms (ms = xi*4 + nu = 0..15): at nu == 0 form t[xi] (8 packed adds), then position ms (2 packed adds)
-    //   event 18: last write
+    //   event 0: read rows 0 and 2 (8 ds_read_b128)      event 1: read row 1      event 8: also read row 3
+    //   event 4 + ms (ms = xi*4 + nu = 0..15): at nu == 0 form t[xi] (8 packed adds), then position ms (2 packed adds)
+    //   event 20: last write
     float4 xr1[4], xr2[4], xra[4], xt[4], xv;
     auto xform_read = [&](int which) {
 #pragma unroll
@@ -177,11 +177,11 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
             if (which == 3) xra[cidx] = sR[x_src + 3 * RW + cidx];
         }
     };
-    auto xform_event = [&](float4* vbuf, int x) {      // x = 0 .. 18
+    auto xform_event = [&](float4* vbuf, int x) {      // x = 0 .. 20
         if (x == 0) xform_read(0);
         else if (x == 1) xform_read(1);
-        else {
-            const int ms = x - 2;
+        else if (x >= 4) {                              // events 2, 3: idle -- the 12 reads (3 KB per lane group) need ~250 cycles
+            const int ms = x - 4;
             if (ms > 0) vbuf[x_dst + (ms - 1) * VPLANE] = xv;      // position ms-1, computed one event ago
             if (ms < 16) {
                 const int xi = ms >> 2, nu = ms & 3;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
         }
         __syncthreads();
 #pragma unroll
-        for (int x = 0; x < 19; ++x) xform_event(sB, x);
+        for (int x = 0; x < 21; ++x) xform_event(sB, x);
     }
 
     for (int u = 0;; ++u) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
                     const int e = qa * 2 + slot;          // staging event 0 .. 63
                     if (e >= C::E_RAW_LOAD && e < C::E_RAW_LOAD + ITER_R) rv[e - C::E_RAW_LOAD] = stage_fetch(rs_n, roff[e - C::E_RAW_LOAD]);
                     if (e >= C::E_RAW_STORE && e < C::E_RAW_STORE + ITER_R) sR[tid + (e - C::E_RAW_STORE) * C::NTHREADS] = rv[e - C::E_RAW_STORE];
-                    if (e >= C::E_XFORM && e < C::E_XFORM + 19) xform_event(vnext, e - C::E_XFORM);
+                    if (e >= C::E_XFORM && e < C::E_XFORM + 21) xform_event(vnext, e - C::E_XFORM);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // MFMAs of this slot: register j = slot of qa, then of qb

@@ -594,6 +594,54 @@ def test_parity_128_frames_every_corner(dev):
     assert corners > 1000 and mismatched_frames == 0
 
 
+_FAMILY_SCRIPT = r"""
+import sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, {repo!r})
+from deepcharuco_amd import weights as W
+from deepcharuco_amd.inference import infer_batch
+from deepcharuco_amd.models.net import dcModel, lModel
+from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+dev = torch.device("cuda", 0)
+frames = np.concatenate([W.synthetic_frames("noise", 4100, 16, 240, 320), W.synthetic_frames("board", 5100, 16, 240, 320)])
+sd = W.synthetic_state_dict("detector", 2024)
+sd["convDb.bias"][16] = np.float32(sd["convDb.bias"][16] + {delta!r})
+dc, rn = lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 2025), dev))
+got = infer_batch(frames, 16, dc, rn, kmax=64)
+h = hashlib.sha256()
+n = 0
+for g in got:
+    a = np.ascontiguousarray(np.asarray(g, dtype=np.float64))
+    h.update(str(a.shape).encode()); h.update(a.tobytes()); n += 0 if a.ndim == 1 else a.shape[0]
+print("RESULT", n, h.hexdigest())
+"""
+
+
+def test_kernel_families_give_identical_corners(dev):
+    """The same 32 frames through the three convolution kernel families -- direct only, 1-D Winograd, 2-D Winograd (the
+    default) -- must give identical corner lists (ids, integer cells, sub-pixel xy): the families differ in fp32 rounding
+    (each is bit-exact against ITS restatement), and the arg-max outputs must not notice.  Each family runs in its own
+    process because the switches are read once per process."""
+    import subprocess
+    import sys
+    frames = np.concatenate([W.synthetic_frames("noise", 4100, 16, 240, 320), W.synthetic_frames("board", 5100, 16, 240, 320)])
+    sd = _calibrated(2024, frames[::4], target_per_frame=14)
+    delta = float(sd["convDb.bias"][16] - W.synthetic_state_dict("detector", 2024)["convDb.bias"][16])
+    script = _FAMILY_SCRIPT.format(repo=REPO, delta=delta)
+    results = {}
+    for name, env in (("direct", {"DCX_WINO": "0", "DCX_WINO2": "0"}), ("wino1d", {"DCX_WINO2": "0"}), ("wino2d", {})):
+        e = dict(os.environ)
+        e.pop("DCX_FORCE_CFG", None)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, f"{name}: {out.stderr[-2000:]}"
+        results[name] = line[0].split()[1:]
+    _report("kernel_families", {k: dict(corners=int(v[0]), sha256=v[1][:16]) for k, v in results.items()})
+    assert int(results["wino2d"][0]) > 200
+    assert results["direct"] == results["wino1d"] == results["wino2d"], results
+
+
 def test_pitched_frame_buffer_through_c_abi(dev, golden_tiny):
     """The C ABI takes a row pitch and a frame stride: frames that are windows of a larger device buffer
     (camera ring buffer with padding) give the same rows as dense frames."""
