@@ -68,10 +68,7 @@ struct DcxWinoCfg {
     static constexpr int RAW_PAD = ITER_R * NTHREADS;  // raw buffer incl. padding slots (they receive zeros)
     static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_PAD) * 16;   // 2 transformed buffers + 1 raw buffer
     static constexpr int STEPS = 3 * (DCX_CCH / 8);    // k-steps per unit: (ky, 8-channel group)
-#ifndef DCX_WINO_DA
-#define DCX_WINO_DA 2
-#endif
-    static constexpr int DA = DCX_WINO_DA;             // weights are requested DA k-steps ahead
+    static constexpr int DA = 2;                       // weights are requested DA k-steps ahead (3 and 4 measured the same)
     static constexpr int RAW_STORE_STEP = 3;           // raw loads are issued in k-step 0 and written to LDS in this step
     static constexpr int NPAIR = 8;                    // 16 MFMAs per k-step: 4 registers j x 4 positions p
     static constexpr int OCC = 2;
