@@ -342,27 +342,17 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         load_b(buf, 0, bq[0]);
         float4* lds_w = sB + (buf ^ 1) * LDSF + tid;   // this thread's slot 0 in the buffer being filled
         float4 pv[STEPS][PPS];
-        // staging address of the piece(s) a step requests, computed in four mini-slots during the step before
+        // staging offsets of the next unit's pieces: the per-piece constants, or (border / overhanging tiles, ONE uniform
+        // branch per unit) the bounds-checked ones.  Nothing inside the k-loop is conditional: per-instruction branches on
+        // "border tile" or "first chunk" cost ~500 cycles per unit (measured on the Winograd kernel, same structure).
         const bool n_interior = tile_interior(nxt);
-        bool p_in[PPS];
-        unsigned poff[PPS];
-        auto off_part = [&](int part, int for_step) {     // part 0: in-bounds predicate, part 1: select the offset
-            if (for_step >= C::LOAD_STEPS) return;
+        unsigned poff[ITER];
 #pragma unroll
-            for (int k = 0; k < PPS; ++k) {
-                const int pi = for_step * PPS + k;
-                if (pi >= ITER) continue;
-                if (n_interior) {                     // uniform: no VALU at all
-                    if (part == 1) poff[k] = p_rel[pi];
-                } else if (part == 0) {
-                    const int ly = nsy0 + p_hy[pi], lx = nsx0 + p_hx[pi];
-                    p_in[k] = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
-                } else {
-                    poff[k] = p_in[k] ? p_rel[pi] : 0x80000000u;   // out of range -> the buffer load returns zeros
-                }
-            }
-        };
-        off_part(0, 0); off_part(1, 0);   // step 0's piece (exposed once per unit)
+        for (int pi = 0; pi < ITER; ++pi) poff[pi] = p_rel[pi];
+        if (!n_interior) {
+#pragma unroll
+            for (int pi = 0; pi < ITER; ++pi) poff[pi] = stage_off(nsy0, nsx0, pi);
+        }
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             int pair = 0;
@@ -374,13 +364,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                     const float4 av4 = aq[step][mt], bv4 = bq[step][nt];
                     const float av = j == 0 ? av4.x : j == 1 ? av4.y : j == 2 ? av4.z : av4.w;
                     const float bv = j == 0 ? bv4.x : j == 1 ? bv4.y : j == 2 ? bv4.z : bv4.w;
-                    if (step == 0 && j == 0 && c == 0) {
-                        // first MFMA of a work item on this accumulator: a zero C operand clears it for free
-                        const dcx_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, zero, 0, 0, 0);
-                    } else {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0);
-                    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0);
                 }
                 ++pair;
                 __builtin_amdgcn_sched_barrier(0);
@@ -400,7 +384,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
 #pragma unroll
                 for (int k = 0; k < PPS; ++k) {
                     const int pi = step * PPS + k;
-                    if (pi < ITER) pv[step][k] = stage_fetch(rs_n, poff[k]);
+                    if (pi < ITER) pv[step][k] = stage_fetch(rs_n, poff[pi]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -415,15 +399,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
             if (pair < C::NPAIR) mfma_pair();
-            // slots E0, E1: the NEXT step's staging address (border tiles only: predicate, then select)
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                off_part(part, step + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (pair < C::NPAIR) mfma_pair();
-            }
-#pragma unroll
-            for (int rest = 6; rest < C::NPAIR; ++rest) mfma_pair();
+            for (int rest = 4; rest < C::NPAIR; ++rest) mfma_pair();
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { a_c0[mt] = aq[STEPS][mt]; a_c1[mt] = aq[STEPS + 1][mt]; }
@@ -547,6 +524,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                     a.part_idx[(size_t)n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
                 }
             }
+        }
+
+        if (c == nch - 1) {   // the next unit starts a new work item
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
 
         if (!has_next) {
