@@ -241,7 +241,11 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
         for (int x = 0; x < 21; ++x) xform_event(sB, x);
     }
 
-    for (int u = 0;; ++u) {
+    int u = 0;
+    // One unit.  `zero_t`: first unit of a work item -- the first MFMA on each accumulator takes C = 0.  The item loop below
+    // runs the first unit and the remaining units from two separate copies of this body (a peeled loop, not a diamond).
+    auto run_unit = [&](auto zero_t) -> bool {
+        constexpr bool ZERO = decltype(zero_t)::value;
         DcxItem nxt = cur;
         int cn = c + 1;
         bool has_next = true;
@@ -313,11 +317,17 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
                     // waits for; the only VALU-written candidates are the weight registers carried over from the previous
                     // unit (possible v_mov copies just before the loop) -> 2 wait states ahead of the unit's first MFMAs.
                     // C is always the previous D of the same accumulator (accumulate chain: no wait states).
-                    // (A C = 0 variant of the first k-step, chosen by one branch per unit, was tried to save the per-item
-                    //  clear: hipcc reconciles the two variants by moving accumulators through VGPRs and scratch -- 535 spills.)
+                    // (A C = 0 variant of the first k-step chosen by a branch INSIDE the unit makes hipcc reconcile the two
+                    //  variants by moving accumulators through VGPRs and scratch -- 535 spills; the peeled first unit below,
+                    //  a separate copy of the whole unit body, does not.)
                     if (qa == 0 && slot == 0) asm volatile("s_nop 1");
-                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pa]) : "v"(av0), "v"(bv0));
-                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pb]) : "v"(av1), "v"(bv1));
+                    if (ZERO && qa < 16 && slot == 0) {   // first touch of these two accumulators in this work item: C = 0
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "+a"(acc[pa]) : "v"(av0), "v"(bv0));
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "+a"(acc[pb]) : "v"(av1), "v"(bv1));
+                    } else {
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pa]) : "v"(av0), "v"(bv0));
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pb]) : "v"(av1), "v"(bv1));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
         for (int d = 0; d < DQ; ++d) a_c[d] = aq[NQ + d];
 
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[6 + 3 * u] = __builtin_amdgcn_s_memtime();
-        if (c == nch - 1) {
+        if (!ZERO && c == nch - 1) {
             // ---- epilogue: 2-D output transform, BN, ReLU (, pool | head), store -----------------------
             // (the MFMAs are inline asm, so the compiler does not know the MFMA -> v_accvgpr_read distance; the code between
             //  the last MFMA and the first read is far longer than the 18 wait states required, the nops make it explicit)
@@ -469,8 +479,6 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
                     a.part_idx[(size_t)cur.n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
                 }
             }
-            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // the epilogue's last v_accvgpr_read is far behind; explicit anyway
-            clear_acc();
         }
 
         if (!has_next) {
@@ -478,11 +486,20 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
                 a.clk_probe[2] = __builtin_amdgcn_s_memtime();
                 a.clk_probe[3] = __builtin_amdgcn_s_memrealtime();
             }
-            break;
+            return false;
         }
         if (cn == 0) w += gstride;
         cur = nxt;
         c = cn;
+        ++u;
+        return true;
+    };
+    // work items: first unit (C = 0), then the remaining nch-1 units (the last one runs the epilogue); nch >= 2
+    for (;;) {
+        run_unit(std::true_type{});
+        bool more = true;
+        while (c != 0 && more) more = run_unit(std::false_type{});
+        if (!more) break;
     }
 }
 
@@ -491,7 +508,7 @@ static int dcx_conv_wino2_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     a.tiles_x = (a.wo + C::TW - 1) / C::TW;
     a.tiles_y = (a.ho + C::TH - 1) / C::TH;
     if (a.w_wino2 == nullptr || a.alpha == nullptr || a.beta == nullptr) return DCX_E_ARG;
-    if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0) return DCX_E_SHAPE;
+    if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0 || a.cin < 2 * DCX_CCH) return DCX_E_SHAPE;   // >= 2 units per work item
     if (C::EPI == DCX_EPI_HEAT && (a.head_w == nullptr || a.part_val == nullptr || a.part_idx == nullptr)) return DCX_E_ARG;
     if (C::EPI != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
     const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
