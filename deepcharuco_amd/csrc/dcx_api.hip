@@ -192,7 +192,7 @@ struct dcx_refiner {
 namespace {
 
 struct DetWs {
-    size_t buf0, buf1, loc, ids, total;
+    size_t buf0, buf1, loc, ids, codes, total;
     int ids_quads;
 };
 DetWs det_layout(int n_ids, int b, int h, int w) {
@@ -204,6 +204,7 @@ DetWs det_layout(int n_ids, int b, int h, int w) {
     L.buf1 = off; off = align_up(off + (size_t)b * 16 * hw * 4, 256);
     L.loc = off;  off = align_up(off + (size_t)b * 68 * cells * 4, 256);
     L.ids = off;  off = align_up(off + (size_t)b * L.ids_quads * 4 * cells * 4, 256);
+    L.codes = off; off = align_up(off + (size_t)b * cells * 4, 256);    // decode scratch: packed arg-max per cell
     L.total = off;
     return L;
 }
@@ -365,7 +366,7 @@ extern "C" int dcx_detector_forward(const dcx_detector* det, const uint8_t* d_fr
     return 0;
 }
 
-extern "C" int dcx_detector_decode(const dcx_detector* det, int batch, int height, int width, const void* d_ws,
+extern "C" int dcx_detector_decode(const dcx_detector* det, int batch, int height, int width, void* d_ws,
                                    int dust_bin, int kmax, int32_t* d_counts, int32_t* d_rows, int32_t* d_loc_argmax,
                                    int32_t* d_ids_argmax, void* stream) {
     if (!det || !d_ws) return DCX_E_ARG;
@@ -373,11 +374,11 @@ extern "C" int dcx_detector_decode(const dcx_detector* det, int batch, int heigh
     const DetWs L = det_layout(det->n_ids, batch, height, width);
     const int hc = height / 8, wc = width / 8;
     const long cells = (long)hc * wc;
-    const char* ws = (const char*)d_ws;
+    char* ws = (char*)d_ws;
     DcxLogitView lv{(const float*)(ws + L.loc), 17 * 4 * cells, 4 * cells, 4, 1};
     DcxLogitView iv{(const float*)(ws + L.ids), (long)L.ids_quads * 4 * cells, 4 * cells, 4, 1};
     return dcx_launch_decode(lv, iv, batch, 65, det->n_ids + 1, hc, wc, dust_bin, kmax, d_counts, d_rows,
-                             d_loc_argmax, d_ids_argmax, (hipStream_t)stream);
+                             d_loc_argmax, d_ids_argmax, (int32_t*)(ws + L.codes), (hipStream_t)stream);
 }
 
 // ---- refiner ----------------------------------------------------------------------------------

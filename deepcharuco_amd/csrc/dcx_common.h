@@ -78,7 +78,7 @@ struct DcxLogitView {
 };
 int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, int n_ids1, int hc, int wc,
                       int dust_bin, int kmax, int32_t* counts, int32_t* rows,
-                      int32_t* loc_argmax, int32_t* ids_argmax, hipStream_t s);
+                      int32_t* loc_argmax, int32_t* ids_argmax, int32_t* codes_scratch, hipStream_t s);
 int dcx_launch_refine_finalize(const float* part_val, const int* part_idx, int tiles, int wo,
                                int max_patches, const int* total, const int32_t* table,
                                int32_t* corners, float* xy, hipStream_t s);

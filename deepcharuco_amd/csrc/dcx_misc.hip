@@ -108,6 +108,77 @@ __device__ __forceinline__ float dcx_logit(const DcxLogitView& v, int b, int c, 
     return v.p[(size_t)b * v.sb + (size_t)(c >> 2) * v.sq + (size_t)cell * v.sp + (size_t)(c & 3) * v.sc];
 }
 
+// per-cell 65-/17-way arg-max (model_utils.py:53-66: first maximum wins) with the dust-bin substitution
+template <bool C4>
+__device__ __forceinline__ void dcx_cell_argmax(const DcxLogitView& loc, const DcxLogitView& ids, int n_loc, int n_ids1,
+                                                int cells, int dust_bin, int b, int cell, int& la, int& ia) {
+    la = 0; ia = 0;
+    if (C4) {
+        // C4 logits [b][quad][cell][4]: one 16-B load per channel quad, lanes on consecutive cells.
+        // Channels are visited in increasing order with a strict '>' so the first maximum wins
+        // (torch.argmax); the zero-filled pad channels of the last quad are never looked at.
+        const float4* lq = reinterpret_cast<const float4*>(loc.p) + (size_t)b * (loc.sb >> 2) + cell;
+        const float4* iq = reinterpret_cast<const float4*>(ids.p) + (size_t)b * (ids.sb >> 2) + cell;
+        float best = -INFINITY;
+        for (int q = 0; 4 * q < n_loc; ++q) {
+            const float4 v = lq[(size_t)q * cells];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * q + k < n_loc && (e[k] > best || (q == 0 && k == 0))) { best = e[k]; la = 4 * q + k; }
+        }
+        best = -INFINITY;
+        for (int q = 0; 4 * q < n_ids1; ++q) {
+            const float4 v = iq[(size_t)q * cells];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * q + k < n_ids1 && (e[k] > best || (q == 0 && k == 0))) { best = e[k]; ia = 4 * q + k; }
+        }
+    } else {
+        float best = dcx_logit(loc, b, 0, cell);
+        for (int c = 1; c < n_loc; ++c) {            // torch.argmax: first maximum wins
+            const float v = dcx_logit(loc, b, c, cell);
+            if (v > best) { best = v; la = c; }
+        }
+        best = dcx_logit(ids, b, 0, cell);
+        for (int c = 1; c < n_ids1; ++c) {
+            const float v = dcx_logit(ids, b, c, cell);
+            if (v > best) { best = v; ia = c; }
+        }
+    }
+    if (la == n_loc - 1) ia = dust_bin;          // where(loc_argmax == 64, dust_bin, ids_argmax)
+}
+
+// ordered compaction of one chunk of 256 cells of frame b (wave ballot + LDS scan); all 256 threads call it
+__device__ __forceinline__ void dcx_compact_chunk(bool fire, int la, int ia, int cell, int wc, int kmax, int b,
+                                                  int* wave_cnt, int* base_s, int32_t* __restrict__ rows) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long m = __ballot(fire);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = *base_s;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (fire) {
+        const int pos = off + before;
+        if (pos < kmax) {
+            const int cy = cell / wc, cx = cell - cy * wc;
+            int4 r;
+            r.x = 8 * cx + (la & 7);                  // xs = 8*ix + loc % 8
+            r.y = 8 * cy + (la >> 3);                 // ys = 8*iy + loc // 8
+            r.z = ia;
+            r.w = cell;
+            reinterpret_cast<int4*>(rows)[(size_t)b * kmax + pos] = r;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) *base_s += total;
+    __syncthreads();
+}
+
+// single-kernel decode: one workgroup per frame (used when the caller has no scratch buffer)
 template <bool C4>
 __global__ __launch_bounds__(256) void dcx_decode_kernel(DcxLogitView loc, DcxLogitView ids, int n_loc, int n_ids1,
                                                            int hc, int wc, int dust_bin, int kmax,
@@ -117,7 +188,7 @@ __global__ __launch_bounds__(256) void dcx_decode_kernel(DcxLogitView loc, DcxLo
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
     const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int cells = hc * wc;
     if (tid == 0) base_s = 0;
     __syncthreads();
@@ -126,78 +197,77 @@ __global__ __launch_bounds__(256) void dcx_decode_kernel(DcxLogitView loc, DcxLo
         bool fire = false;
         int la = 0, ia = 0;
         if (cell < cells) {
-            if (C4) {
-                // C4 logits [b][quad][cell][4]: one 16-B load per channel quad, lanes on consecutive cells.
-                // Channels are visited in increasing order with a strict '>' so the first maximum wins
-                // (torch.argmax); the zero-filled pad channels of the last quad are never looked at.
-                const float4* lq = reinterpret_cast<const float4*>(loc.p) + (size_t)b * (loc.sb >> 2) + cell;
-                const float4* iq = reinterpret_cast<const float4*>(ids.p) + (size_t)b * (ids.sb >> 2) + cell;
-                float best = -INFINITY;
-                for (int q = 0; 4 * q < n_loc; ++q) {
-                    const float4 v = lq[(size_t)q * cells];
-                    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (4 * q + k < n_loc && (e[k] > best || (q == 0 && k == 0))) { best = e[k]; la = 4 * q + k; }
-                }
-                best = -INFINITY;
-                for (int q = 0; 4 * q < n_ids1; ++q) {
-                    const float4 v = iq[(size_t)q * cells];
-                    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (4 * q + k < n_ids1 && (e[k] > best || (q == 0 && k == 0))) { best = e[k]; ia = 4 * q + k; }
-                }
-            } else {
-                float best = dcx_logit(loc, b, 0, cell);
-                for (int c = 1; c < n_loc; ++c) {            // torch.argmax: first maximum wins
-                    const float v = dcx_logit(loc, b, c, cell);
-                    if (v > best) { best = v; la = c; }
-                }
-                best = dcx_logit(ids, b, 0, cell);
-                for (int c = 1; c < n_ids1; ++c) {
-                    const float v = dcx_logit(ids, b, c, cell);
-                    if (v > best) { best = v; ia = c; }
-                }
-            }
-            if (la == n_loc - 1) ia = dust_bin;          // where(loc_argmax == 64, dust_bin, ids_argmax)
+            dcx_cell_argmax<C4>(loc, ids, n_loc, n_ids1, cells, dust_bin, b, cell, la, ia);
             fire = ia != dust_bin;
             if (loc_argmax) loc_argmax[(size_t)b * cells + cell] = la;
             if (ids_argmax) ids_argmax[(size_t)b * cells + cell] = ia;
         }
-        const unsigned long long m = __ballot(fire);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = base_s;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        if (fire) {
-            const int pos = off + before;
-            if (pos < kmax) {
-                const int cy = cell / wc, cx = cell - cy * wc;
-                int4 r;
-                r.x = 8 * cx + (la & 7);                  // xs = 8*ix + loc % 8
-                r.y = 8 * cy + (la >> 3);                 // ys = 8*iy + loc // 8
-                r.z = ia;
-                r.w = cell;
-                reinterpret_cast<int4*>(rows)[(size_t)b * kmax + pos] = r;
-            }
+        dcx_compact_chunk(fire, la, ia, cell, wc, kmax, b, wave_cnt, &base_s, rows);
+    }
+    if (tid == 0) counts[b] = base_s;
+}
+
+// two-phase decode (pipeline path): the arg-max of every cell of the batch in parallel (HBM-bound, 328 B per cell) ...
+template <bool C4>
+__global__ __launch_bounds__(256) void dcx_cell_argmax_kernel(DcxLogitView loc, DcxLogitView ids, int n_loc, int n_ids1,
+                                                                int cells, int dust_bin, int32_t* __restrict__ codes,
+                                                                int32_t* __restrict__ loc_argmax,
+                                                                int32_t* __restrict__ ids_argmax) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= cells) return;
+    int la, ia;
+    dcx_cell_argmax<C4>(loc, ids, n_loc, n_ids1, cells, dust_bin, b, cell, la, ia);
+    codes[(size_t)b * cells + cell] = la | (ia << 8);
+    if (loc_argmax) loc_argmax[(size_t)b * cells + cell] = la;
+    if (ids_argmax) ids_argmax[(size_t)b * cells + cell] = ia;
+}
+
+// ... then the ordered compaction of each frame's firing cells (one workgroup per frame over 4 bytes per cell)
+__global__ __launch_bounds__(256) void dcx_compact_kernel(const int32_t* __restrict__ codes, int hc, int wc, int dust_bin,
+                                                            int kmax, int32_t* __restrict__ counts,
+                                                            int32_t* __restrict__ rows) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int cells = hc * wc;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < cells; c0 += 256) {
+        const int cell = c0 + tid;
+        bool fire = false;
+        int la = 0, ia = 0;
+        if (cell < cells) {
+            const int code = codes[(size_t)b * cells + cell];
+            la = code & 255; ia = code >> 8;
+            fire = ia != dust_bin;
         }
-        __syncthreads();
-        if (tid == 0) base_s += total;
-        __syncthreads();
+        dcx_compact_chunk(fire, la, ia, cell, wc, kmax, b, wave_cnt, &base_s, rows);
     }
     if (tid == 0) counts[b] = base_s;
 }
 
 int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, int n_ids1, int hc, int wc,
                       int dust_bin, int kmax, int32_t* counts, int32_t* rows,
-                      int32_t* loc_argmax, int32_t* ids_argmax, hipStream_t s) {
+                      int32_t* loc_argmax, int32_t* ids_argmax, int32_t* codes_scratch, hipStream_t s) {
     if (!loc.p || !ids.p || !counts || !rows) return DCX_E_ARG;
-    if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0 || n_loc != 65 || n_ids1 < 2) return DCX_E_SHAPE;
+    if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0 || n_loc != 65 || n_ids1 < 2 || n_ids1 > 256) return DCX_E_SHAPE;
     const bool c4 = loc.sc == 1 && loc.sp == 4 && ids.sc == 1 && ids.sp == 4 && loc.sq == 4L * hc * wc && ids.sq == 4L * hc * wc
                     && (loc.sb & 3) == 0 && (ids.sb & 3) == 0;
+    if (codes_scratch != nullptr) {     // [batch][hc*wc] int32 of scratch: arg-max of all cells in parallel, then compaction
+        const int cells = hc * wc;
+        const dim3 grid((unsigned)((cells + 255) / 256), (unsigned)batch);
+        if (c4)
+            hipLaunchKernelGGL(dcx_cell_argmax_kernel<true>, grid, dim3(256), 0, s, loc, ids, n_loc, n_ids1, cells, dust_bin,
+                               codes_scratch, loc_argmax, ids_argmax);
+        else
+            hipLaunchKernelGGL(dcx_cell_argmax_kernel<false>, grid, dim3(256), 0, s, loc, ids, n_loc, n_ids1, cells, dust_bin,
+                               codes_scratch, loc_argmax, ids_argmax);
+        hipLaunchKernelGGL(dcx_compact_kernel, dim3((unsigned)batch), dim3(256), 0, s, codes_scratch, hc, wc, dust_bin, kmax,
+                           counts, rows);
+        return (int)hipGetLastError();
+    }
     if (c4)
         hipLaunchKernelGGL(dcx_decode_kernel<true>, dim3((unsigned)batch), dim3(256), 0, s, loc, ids, n_loc, n_ids1, hc, wc,
                            dust_bin, kmax, counts, rows, loc_argmax, ids_argmax);
@@ -214,7 +284,7 @@ extern "C" int dcx_pred_to_keypoints(const float* d_loc, const float* d_ids, int
     DcxLogitView lv{d_loc, (long)n_loc * cells, 4 * cells, 1, cells};
     DcxLogitView iv{d_ids, (long)n_ids1 * cells, 4 * cells, 1, cells};
     return dcx_launch_decode(lv, iv, batch, n_loc, n_ids1, hc, wc, dust_bin, kmax, d_counts, d_rows,
-                             d_loc_argmax, d_ids_argmax, (hipStream_t)stream);
+                             d_loc_argmax, d_ids_argmax, nullptr, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -82,10 +82,12 @@ int dcx_detector_forward(const dcx_detector* det,
  * id, cell = cy*Wc + cx} in raster order per frame.  d_counts[b] = number of firing cells
  * (may exceed kmax; only the first kmax rows are stored).  d_rows: int32 [B][kmax][4].
  * Optional dense maps d_loc_argmax / d_ids_argmax: int32 [B][Hc][Wc] (ids map is post-mask).
- * dcx_detector_decode reads the logits the preceding dcx_detector_forward left in d_ws;
- * dcx_pred_to_keypoints takes caller NCHW logits (the reference's own signature).        */
+ * dcx_detector_decode reads the logits the preceding dcx_detector_forward left in d_ws and
+ * uses 4 bytes per cell of scratch in it (arg-max of all cells in parallel, then one ordered
+ * compaction per frame); dcx_pred_to_keypoints takes caller NCHW logits (the reference's own
+ * signature) and needs no scratch (one workgroup per frame).                                */
 int dcx_detector_decode(const dcx_detector* det, int batch, int height, int width,
-                        const void* d_ws, int dust_bin, int kmax,
+                        void* d_ws, int dust_bin, int kmax,
                         int32_t* d_counts, int32_t* d_rows,
                         int32_t* d_loc_argmax, int32_t* d_ids_argmax, void* stream);
 int dcx_pred_to_keypoints(const float* d_loc_nchw, const float* d_ids_nchw,
