@@ -292,29 +292,41 @@ extern "C" int dcx_pred_to_keypoints(const float* d_loc, const float* d_ids, int
 __global__ __launch_bounds__(256) void dcx_patch_table_kernel(const int32_t* __restrict__ counts,
                                                                 const int32_t* __restrict__ rows, int batch, int kmax,
                                                                 int32_t* __restrict__ table, int32_t* __restrict__ total) {
-    __shared__ int sc[256];
+    __shared__ int s_cnt[256], s_start[256];
+    __shared__ int wave_tot[4];
     __shared__ int carry;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
     for (int b0 = 0; b0 < batch; b0 += 256) {
         const int b = b0 + tid;
         const int c = b < batch ? min(counts[b], kmax) : 0;
-        sc[tid] = c;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {      // Hillis-Steele inclusive scan
-            const int v = tid >= d ? sc[tid - d] : 0;
-            __syncthreads();
-            sc[tid] += v;
-            __syncthreads();
+        // exclusive scan of the chunk's 256 counts: shuffle scan inside each wave, then the 4 wave totals
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
         }
-        const int start = carry + sc[tid] - c;
-        for (int k = 0; k < c; ++k) {
-            const int4 r = reinterpret_cast<const int4*>(rows)[(size_t)b * kmax + k];
-            reinterpret_cast<int4*>(table)[start + k] = make_int4(b, r.x, r.y, b * kmax + k);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        s_cnt[tid] = c;
+        s_start[tid] = off + incl - c;
+        __syncthreads();
+        // all 256 threads copy the (frame, k) rows of the chunk
+        const int nb = min(256, batch - b0);
+        for (int idx = tid; idx < nb * kmax; idx += 256) {
+            const int bl = idx / kmax, k = idx - bl * kmax;
+            if (k < s_cnt[bl]) {
+                const int bb = b0 + bl;
+                const int4 r = reinterpret_cast<const int4*>(rows)[(size_t)bb * kmax + k];
+                reinterpret_cast<int4*>(table)[s_start[bl] + k] = make_int4(bb, r.x, r.y, bb * kmax + k);
+            }
         }
         __syncthreads();
-        if (tid == 255) carry += sc[255];
+        if (tid == 0) carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         __syncthreads();
     }
     if (tid == 0) *total = carry;
