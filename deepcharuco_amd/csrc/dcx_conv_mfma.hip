@@ -12,32 +12,37 @@ namespace {
 struct CfgEntry {
     int cout_tile, cap, th, tw, ks, pool, epi, acc_tiles;
     int inlane;   // pooled layout with the 2x2 window inside one lane (MT=1, NT=4): no cross-lane max
+    int group;    // images per work item (2-D Winograd grouped tiles for small maps); 1 otherwise
     int wino;     // 1: 1-D Winograd F(2,3) kernel (dcx_conv_wino.h), 2/3 of the MFMAs; 2: 2-D F(2x2,3x3) (dcx_conv_wino2.h), 4/9
     int (*launch)(DcxConvArgs, hipStream_t);
     const char* name;
 };
 
 #define DCX_CFG(WM, WN, MT, NT, TH, TW, KS, POOL, EPI)                                              \
-    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT, ((POOL) != 0 && MT == 1 && NT == 4) ? 1 : 0, 0, \
+    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT, ((POOL) != 0 && MT == 1 && NT == 4) ? 1 : 0, 1, 0, \
       &dcx_conv_launch_cfg<DcxConvCfg<WM, WN, MT, NT, TH, TW, KS, (POOL) != 0, EPI>>,                 \
       "dcx_conv_mfma_kernel<DcxConvCfg<" #WM "," #WN "," #MT "," #NT "," #TH "," #TW "," #KS "," #POOL "," #EPI ">>" }
 
 #define DCX_WCFG(WM, WN, TH, TW, POOL)                                                                \
-    { WM * 32, WN * 64, TH, TW, 3, POOL, DCX_EPI_BNRELU, 4, 0, 1,                                          \
+    { WM * 32, WN * 64, TH, TW, 3, POOL, DCX_EPI_BNRELU, 4, 0, 1, 1,                                        \
       &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, (POOL) != 0>>,                                  \
       "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW "," #POOL ">>" }
 #define DCX_WCFG_HEAT(WM, WN, TH, TW)                                                                  \
-    { WM * 32, WN * 64, TH, TW, 3, 0, DCX_EPI_HEAT, 4, 0, 1,                                               \
+    { WM * 32, WN * 64, TH, TW, 3, 0, DCX_EPI_HEAT, 4, 0, 1, 1,                                             \
       &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, false, DCX_EPI_HEAT>>,                          \
       "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW ",0,DCX_EPI_HEAT>>" }
 
 #define DCX_W2CFG(TH, TW, POOL)                                                                       \
-    { 64, 256, TH, TW, 3, POOL, DCX_EPI_BNRELU, 16, 0, 2,                                                   \
+    { 64, 256, TH, TW, 3, POOL, DCX_EPI_BNRELU, 16, 0, 1, 2,                                                 \
       &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, (POOL) != 0>>,                                        \
       "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW "," #POOL ">>" }
 
+#define DCX_W2CFG_G(TH, TW, G)                                                                        \
+    { 64, 256, TH, TW, 3, 0, DCX_EPI_BNRELU, 16, 0, G, 2,                                                   \
+      &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, false, DCX_EPI_BNRELU, G>>,                           \
+      "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW ",0,DCX_EPI_BNRELU," #G ">>" }
 #define DCX_W2CFG_HEAT(TH, TW)                                                                        \
-    { 64, 256, TH, TW, 3, 0, DCX_EPI_HEAT, 16, 0, 2,                                                        \
+    { 64, 256, TH, TW, 3, 0, DCX_EPI_HEAT, 16, 0, 1, 2,                                                      \
       &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, false, DCX_EPI_HEAT>>,                                \
       "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW ",0,DCX_EPI_HEAT>>" }
 
@@ -87,6 +92,7 @@ const CfgEntry kCfgs[] = {
     DCX_W2CFG(16, 16, 1),
     DCX_W2CFG(8, 32, 1),
     DCX_W2CFG_HEAT(16, 16),
+    DCX_W2CFG_G(8, 8, 4),     // four whole 8x8 maps (RefineNet after its pool) per work item
 };
 
 int dcx_wino2_enabled() {   // on by default; DCX_WINO2=0 keeps the 1-D Winograd / direct kernels (A/B runs)
@@ -119,7 +125,7 @@ int dcx_big_tiles_disabled() {
 // accounted for -- plus ~520 cycles per 16-channel unit (barrier, first LDS wait, scalar bookkeeping) and an epilogue
 // of ~40 (60 pooled) cycles per accumulator register.  Big tiles win when there is plenty of work (less halo, fewer
 // units), the 64x64 S tile when a launch has few items (bs=1, 30x40 maps) or would leave CUs idle in the last round.
-const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int pool, int epi) {
+const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int pool, int epi, int allow_group = 1) {
     const CfgEntry* best = nullptr;
     double best_cost = 0.0;
     const int n_cu = dcx_device_cu_count();
@@ -128,7 +134,8 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
     const char* force = getenv("DCX_FORCE_CFG");
     if (force != nullptr && force[0] != 0) {
         for (const CfgEntry& c : kCfgs)
-            if (strcmp(c.name, force) == 0 && c.ks == ks && c.pool == pool && c.epi == epi && cout_pad % c.cout_tile == 0)
+            if (strcmp(c.name, force) == 0 && c.ks == ks && c.pool == pool && c.epi == epi && cout_pad % c.cout_tile == 0 &&
+                (c.group == 1 || (allow_group && ho <= c.th && wo <= c.tw)))
                 return &c;
     }
     for (const CfgEntry& c : kCfgs) {
@@ -137,9 +144,10 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         if (c.inlane && !dcx_inlane_pool_enabled()) continue;
         if (c.wino == 1 && !dcx_wino_enabled()) continue;
         if (c.wino == 2 && !dcx_wino2_enabled()) continue;
+        if (c.group > 1 && (!allow_group || ho > c.th || wo > c.tw)) continue;   // grouped tiles: whole small maps only
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
         if (c.cap > 256 && (dcx_big_tiles_disabled() || (double)ho * wo / ((double)tiles * c.cap) < 0.999)) continue;
-        const double items = (double)n * (cout_pad / c.cout_tile) * tiles;
+        const double items = (double)((n + c.group - 1) / c.group) * (cout_pad / c.cout_tile) * tiles;
         const int units = cin / DCX_CCH;
         const int steps = (c.wino ? 3 : ks * ks) * (DCX_CCH / 8);   // Winograd: (ky, 8 channels), 4 positions inside the step
         // per-unit overhead: barrier + first LDS wait + bookkeeping (520); the Winograd units also pay their input
@@ -265,7 +273,8 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
     if (epi != DCX_EPI_RAW && (a.alpha == nullptr || a.beta == nullptr)) return DCX_E_ARG;
     if (pool && ((a.ho | a.wo) & 1)) return DCX_E_SHAPE;
     // the fused-head launch must use the tiling dcx_conv_heat_tiles() sized part_val / part_idx for
-    const CfgEntry* c = pick(epi == DCX_EPI_HEAT ? (1 << 20) : a.n, a.cin, a.ho, a.wo, a.cout_pad, ks, pool, epi);
+    const CfgEntry* c = pick(epi == DCX_EPI_HEAT ? (1 << 20) : a.n, a.cin, a.ho, a.wo, a.cout_pad, ks, pool, epi,
+                             a.ups == 0 && a.pad == 1);   // grouped tiles: same-size convolutions read without up-sampling
     if (c == nullptr) return DCX_E_SHAPE;
     if (!g_prof || (g_prof_filter >= 0 && g_prof_filter != (int)(c - kCfgs))) return c->launch(a, stream);
     ProfRec r;

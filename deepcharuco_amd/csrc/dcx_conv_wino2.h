@@ -25,18 +25,21 @@
 #pragma once
 #include "dcx_conv_wino.h"
 
-template <int TH_, int TW_, bool POOL_, int EPI_ = DCX_EPI_BNRELU>
+template <int TH_, int TW_, bool POOL_, int EPI_ = DCX_EPI_BNRELU, int G_ = 1>
 struct DcxWino2Cfg {
     static constexpr int TH = TH_, TW = TW_;
+    static constexpr int G = G_;                           // images per workgroup tile: G > 1 packs G whole small maps
+                                                           // (<= TH x TW each, e.g. RefineNet's 8x8) into the 64 tiles
     static constexpr bool POOL = POOL_;
     static constexpr int EPI = EPI_;
     static constexpr int NTHREADS = 256;
     static constexpr int COUT_TILE = 64;
     static constexpr int TY = TH / 2, TX = TW / 2;         // 2x2 output tiles of the workgroup tile
-    static constexpr int NTILES = TY * TX;                 // <= 64
+    static constexpr int TPI = TY * TX;                    // 2x2 tiles per image region
+    static constexpr int NTILES = G * TPI;                 // <= 64
     static constexpr int HH = TH + 2, RW = TW + 2;         // raw input rows / columns
     static constexpr int CQC = DCX_CCH / 4;
-    static constexpr int RAW = CQC * HH * RW;
+    static constexpr int RAW = G * CQC * HH * RW;          // [image][cq][row][col]
     static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;
     static constexpr int RAW_PAD = ITER_R * NTHREADS;
     static constexpr int VPLANE = CQC * 64;                // float4 per position: [cq][tile]
@@ -54,8 +57,9 @@ struct DcxWino2Cfg {
     static constexpr int E_XFORM = 32;                     // mid barrier before this event; the transform follows
     static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 64 && NTILES > 32, "tile must hold 33..64 2x2 tiles");
     static_assert(ITER_R <= 8 && E_RAW_STORE + ITER_R <= E_XFORM, "raw staging does not fit the schedule");
-    static_assert(LDS_BYTES + 6144 <= 160 * 1024, "LDS tile too large");
+    static_assert(LDS_BYTES + 1536 <= 160 * 1024, "LDS tile too large");      // + per-launch epilogue constants (checked at launch)
     static_assert(EPI == DCX_EPI_BNRELU || (EPI == DCX_EPI_HEAT && !POOL), "unsupported epilogue");
+    static_assert(G == 1 || (EPI == DCX_EPI_BNRELU && !POOL), "grouped tiles: plain BN + ReLU layers only");
 };
 
 template <class C>
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
     const int n_ct = a.cout_pad / C::COUT_TILE;
     int n_eff = a.n;
     if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
-    const int total = n_eff * n_ct * tiles;
+    const int total = ((n_eff + C::G - 1) / C::G) * n_ct * tiles;      // G > 1: one work item covers G images (tiles == 1)
     int w = blockIdx.x;
     if (w >= total) return;
     if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
     // ---- the lane's 2x2 output tile ---------------------------------------------------------------
     const int qt = wn * 32 + l31;
     const bool qok = qt < C::NTILES;
-    const int qty = qt / TX, qtx = qt - qty * TX;
+    const int q_img = qt / C::TPI, q_t = qt - q_img * C::TPI;     // image inside the group (0 when G == 1)
+    const int qty = q_t / TX, qtx = q_t - qty * TX;
     const int tile_b = half * 64 + (qok ? qt : 0);        // + (pos * CQC + 2s) * 64  ->  sV index of the B operand
 
     // ---- operand fetch ---------------------------------------------------------------------------
@@ -122,30 +127,41 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
     // ---- staging ----------------------------------------------------------------------------------
     int r_hy[ITER_R], r_hx[ITER_R];
     unsigned r_rel[ITER_R];
+    const unsigned in_img_stride = (unsigned)a.in_cq_total * (unsigned)(a.hin * a.win);   // float4 between images
 #pragma unroll
     for (int k = 0; k < ITER_R; ++k) {
         const int idx = tid + k * C::NTHREADS;
-        const int cq = idx / (C::HH * RW);
-        const int hp = idx - cq * (C::HH * RW);
+        const int img = idx / (CQC * C::HH * RW);
+        const int rem = idx - img * (CQC * C::HH * RW);
+        const int cq = rem / (C::HH * RW);
+        const int hp = rem - cq * (C::HH * RW);
         r_hy[k] = hp / RW;
         r_hx[k] = hp - r_hy[k] * RW;
         const int prow = ((r_hy[k] - a.pad) >> a.ups) + a.pad, pcol = ((r_hx[k] - a.pad) >> a.ups) + a.pad;
-        r_rel[k] = idx < C::RAW ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
+        r_rel[k] = idx < C::RAW ? ((unsigned)img * in_img_stride + (unsigned)((cq * a.hin + prow) * a.win + pcol)) * 16u : 0x80000000u;
+        if (C::G > 1) {
+            // a grouped tile always starts at pixel (0, 0) of its images: the zero-padding predicate is a per-piece constant
+            const int ly = r_hy[k] - a.pad, lx = r_hx[k] - a.pad;
+            if (!((unsigned)ly < (unsigned)(a.hin << a.ups) && (unsigned)lx < (unsigned)(a.win << a.ups))) r_rel[k] = 0x80000000u;
+            r_hy[k] = img;      // what the per-unit check needs for grouped tiles: which image of the group the piece reads
+        }
     }
     float4* sR = sB + 2 * LDSF;
     // transform piece of this thread: (cq, tile) = (tid / 64, tid % 64); tiles past the end redo the last tile
     const int x_cq = tid >> 6;
     const int x_tile = min(tid & 63, C::NTILES - 1);
-    const int x_ty = x_tile / TX, x_tx = x_tile - x_ty * TX;
-    const int x_src = (x_cq * C::HH + 2 * x_ty) * RW + 2 * x_tx;     // raw index of the window's top-left pixel
+    const int x_img = x_tile / C::TPI, x_t = x_tile - x_img * C::TPI;
+    const int x_ty = x_t / TX, x_tx = x_t - x_ty * TX;
+    const int x_src = ((x_img * CQC + x_cq) * C::HH + 2 * x_ty) * RW + 2 * x_tx;     // raw index of the window's top-left pixel
     const int x_dst = x_cq * 64 + x_tile;                            // + pos * VPLANE
     auto unit_rsrc = [&](const DcxItem& it, int c) {
         const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
-        const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
+        const float* base = a.in + (((size_t)it.n * C::G * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
                                     + tile_off) * 4;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
     };
     auto tile_interior = [&](const DcxItem& it) {
+        if (C::G > 1) return (it.n + 1) * C::G <= a.n;     // all images of the group exist (spatial padding is folded into r_rel)
         const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
         return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + RW <= wl;
     };
@@ -233,7 +249,8 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
 #pragma unroll
         for (int k = 0; k < ITER_R; ++k) {
             const int ly = sy0 + r_hy[k], lx = sx0 + r_hx[k];
-            const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+            const bool inb = C::G > 1 ? (cur.n * C::G + r_hy[k] < a.n)
+                                      : ((unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl);
             sR[tid + k * C::NTHREADS] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
         }
         __syncthreads();
@@ -277,7 +294,9 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
 #pragma unroll
             for (int k = 0; k < ITER_R; ++k) {
                 const int ly = nsy0 + r_hy[k], lx = nsx0 + r_hx[k];
-                roff[k] = ((unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl) ? r_rel[k] : 0x80000000u;
+                const bool inb = C::G > 1 ? (nxt.n * C::G + r_hy[k] < a.n)
+                                          : ((unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl);
+                roff[k] = inb ? r_rel[k] : 0x80000000u;
             }
         }
         // Positions are processed in pairs (qa, qb = qa + 1): 8 MFMAs alternating between the two accumulators, one slot
@@ -349,11 +368,13 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
             const unsigned plane = (unsigned)(hs * ws);
             const int cq_w0 = (cur.ct * C::COUT_TILE >> 2) + wm * 8;
             char* obase = reinterpret_cast<char*>(a.out)
-                        + ((size_t)cur.n * a.out_cq_total + a.out_cq_off + cq_w0) * (size_t)plane * 16;
-            const bool okr0 = qok && oy0 < a.ho, okr1 = qok && oy0 + 1 < a.ho;
+                        + ((size_t)cur.n * C::G * a.out_cq_total + a.out_cq_off + cq_w0) * (size_t)plane * 16;
+            const bool img_ok = C::G == 1 || cur.n * C::G + q_img < n_eff;
+            const bool okr0 = qok && img_ok && oy0 < a.ho, okr1 = qok && img_ok && oy0 + 1 < a.ho;
             const bool okc0 = ox0 < a.wo, okc1 = ox0 + 1 < a.wo;
-            const unsigned lane_off = C::POOL ? ((unsigned)half * plane + (unsigned)((oy0 >> 1) * ws + (ox0 >> 1))) * 16u
-                                              : ((unsigned)half * plane + (unsigned)(oy0 * ws + ox0)) * 16u;
+            const unsigned lane_off = (C::POOL ? ((unsigned)half * plane + (unsigned)((oy0 >> 1) * ws + (ox0 >> 1))) * 16u
+                                               : ((unsigned)half * plane + (unsigned)(oy0 * ws + ox0)) * 16u)
+                                    + (C::G > 1 ? (unsigned)q_img * (unsigned)a.out_cq_total * plane * 16u : 0u);
             float hsum[4] = {0.f, 0.f, 0.f, 0.f};
             // Output transform, position-outer: y[k = 2i+j] = sum over positions p = xi*4 + nu (ascending) of
             // AT[i][xi] * AT[j][nu] * m[p], AT = [[1,1,1,0],[0,1,-1,-1]] -- the first non-zero term initialises, the others
@@ -511,7 +532,8 @@ static int dcx_conv_wino2_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0 || a.cin < 2 * DCX_CCH) return DCX_E_SHAPE;   // >= 2 units per work item
     if (C::EPI == DCX_EPI_HEAT && (a.head_w == nullptr || a.part_val == nullptr || a.part_idx == nullptr)) return DCX_E_ARG;
     if (C::EPI != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
-    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
+    if (C::G > 1 && (a.tiles_x != 1 || a.tiles_y != 1 || a.ups != 0 || a.hin + 2 > C::HH || a.win + 2 > C::RW)) return DCX_E_SHAPE;
+    const long items = (long)((a.n + C::G - 1) / C::G) * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
     const long resident = (long)dcx_device_cu_count();      // one workgroup per CU
     const long blocks = items < resident ? items : resident;
