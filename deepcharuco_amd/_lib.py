@@ -97,6 +97,19 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def csrc_sha256() -> str:
+    """Hash of the kernel sources (csrc/*.hip, *.h): stamps measurements that are only valid for these kernels
+    (profiles/pmc_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def check(rc: int, where: str) -> None:
     if rc != 0:
         raise DcxError(rc, where)

@@ -249,7 +249,7 @@ extern "C" const char* dcx_error_string(int code) {
         case DCX_E_ARG: return "DCX_E_ARG: null pointer or bad scalar argument";
         case DCX_E_SHAPE: return "DCX_E_SHAPE: unsupported shape (H/W must be multiples of 8, patches 24x24, ...)";
         case DCX_E_WS: return "DCX_E_WS: workspace too small";
-        case DCX_E_NIDS: return "DCX_E_NIDS: dust_bin / n_ids mismatch";
+        case DCX_E_NIDS: return "DCX_E_NIDS: n_ids outside [1, 62] or dust_bin outside [0, 255]";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dcx error";
     }
 }

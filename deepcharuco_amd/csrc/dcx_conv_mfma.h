@@ -548,7 +548,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     }
 }
 
-int dcx_device_cu_count();   // dcx_conv_mfma.hip
+int dcx_device_cu_count();   // dcx_conv_mfma.hip: CUs of the CURRENT device (cached per device)
+constexpr int DCX_MAX_DEVICES = 64;
+int dcx_current_device();    // hipGetDevice() clamped to [0, DCX_MAX_DEVICES)
 int dcx_occupancy_override();
 
 template <class C>
@@ -561,11 +563,12 @@ static int dcx_conv_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const int occ_env = dcx_occupancy_override();                      // tuning knob (DCX_OCC), 0 = default
     const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);   // persistent workgroups
     const long blocks = items < resident ? items : resident;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[DCX_MAX_DEVICES] = {};      // the attribute is per device (multi-GPU processes)
+    const int dev_i = dcx_current_device();
+    if (!attr_set[dev_i]) {
         DCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcx_conv_mfma_kernel<C>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES + 8192)));
-        attr_set = true;
+        attr_set[dev_i] = true;
     }
     const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 16;   // halo double buffer + 4 per-channel parameter arrays
     if (lds > 160 * 1024) return DCX_E_SHAPE;

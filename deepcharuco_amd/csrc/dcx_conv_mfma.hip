@@ -243,17 +243,23 @@ extern "C" int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, d
 // cout <= 64 uses the 64-cout wave layout; anything larger is padded to the 128-cout layouts' multiple.
 int dcx_conv_cout_pad(int cout) { return cout <= 64 ? 64 : (cout + 127) / 128 * 128; }
 
+int dcx_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < DCX_MAX_DEVICES ? dev : DCX_MAX_DEVICES - 1;
+}
+
 int dcx_device_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
+    static int cus[DCX_MAX_DEVICES] = {};      // per device: a process may drive several GPUs (dcModel.to('cuda:1'))
+    const int dev = dcx_current_device();
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus[dev] = v;
         else
-            cus = 256;   // MI355X
+            cus[dev] = 256;   // MI355X
     }
-    return cus;
+    return cus[dev];
 }
 
 int dcx_occupancy_override() {

@@ -507,11 +507,12 @@ static int dcx_conv_wino_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const int occ_env = dcx_occupancy_override();
     const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);
     const long blocks = items < resident ? items : resident;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[DCX_MAX_DEVICES] = {};      // the attribute is per device (multi-GPU processes)
+    const int dev_i = dcx_current_device();
+    if (!attr_set[dev_i]) {
         DCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcx_conv_wino_kernel<C>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES + 8192)));
-        attr_set = true;
+        attr_set[dev_i] = true;
     }
     if (C::EPI == DCX_EPI_HEAT && (a.head_w == nullptr || a.part_val == nullptr || a.part_idx == nullptr)) return DCX_E_ARG;
     if (C::EPI != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;

@@ -539,11 +539,12 @@ static int dcx_conv_wino2_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const long blocks = items < resident ? items : resident;
     const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 12;
     if (lds > 160 * 1024) return DCX_E_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[DCX_MAX_DEVICES] = {};      // the attribute is per device (multi-GPU processes)
+    const int dev_i = dcx_current_device();
+    if (!attr_set[dev_i]) {
         DCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcx_conv_wino2_kernel<C>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[dev_i] = true;
     }
     hipLaunchKernelGGL((dcx_conv_wino2_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), lds, stream, a);
     return (int)hipGetLastError();

@@ -253,6 +253,10 @@ int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, 
                       int32_t* loc_argmax, int32_t* ids_argmax, int32_t* codes_scratch, hipStream_t s) {
     if (!loc.p || !ids.p || !counts || !rows) return DCX_E_ARG;
     if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0 || n_loc != 65 || n_ids1 < 2 || n_ids1 > 256) return DCX_E_SHAPE;
+    // dust_bin is the reference's free parameter `dust_bin_ids` (model_utils.py:76,111): cells whose (masked) id equals it
+    // do not fire.  Any value in [0, 255] has exactly the reference's semantics here (it need not equal n_ids); values
+    // outside cannot be an id at all and would not survive the packed (loc | id << 8) code.
+    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
     const bool c4 = loc.sc == 1 && loc.sp == 4 && ids.sc == 1 && ids.sp == 4 && loc.sq == 4L * hc * wc && ids.sq == 4L * hc * wc
                     && (loc.sb & 3) == 0 && (ids.sb & 3) == 0;
     if (codes_scratch != nullptr) {     // [batch][hc*wc] int32 of scratch: arg-max of all cells in parallel, then compaction

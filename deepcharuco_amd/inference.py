@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .imgproc import bgr2gray
-from .models._handles import Workspace, require_cuda
+from .models._handles import require_cuda
 from .models.model_utils import extract_patches, pre_bgr_image, pred_to_keypoints
 from .models.net import dcModel, lModel
 from .models.refinenet import RefineNet, lRefineNet
@@ -67,12 +67,14 @@ def _unwrap(deepc, refinenet):
     return det, ref
 
 
-_ws = Workspace()
-
-
 def infer_batch_device(frames: torch.Tensor, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Enqueue detect+refine for a batch of GPU-resident gray frames; no host synchronisation.
+
+    Scratch memory: by default a buffer owned by the detector object and keyed by the current HIP stream (so several
+    streams / threads may drive one model pair concurrently, each on its own stream); pass ``ws`` (uint8 GPU tensor of
+    at least ``dcx_pipeline_workspace_bytes`` bytes) to manage it yourself.  ``out`` (optional) must be a contiguous
+    int32 tensor of exactly ``packed_len`` elements on the model's GPU.
 
     frames: (B,H,W) uint8 on the GPU.  Returns the packed result tensor (flat int32, on the GPU), one
     allocation so that one D2H (or one all-gather) moves everything:
@@ -91,11 +93,16 @@ def infer_batch_device(frames: torch.Tensor, dust_bin_ids: int, deepc, refinenet
         nbytes = L.dcx_pipeline_workspace_bytes(det.handle, ref.handle if ref else None, b, h, w, kmax)
         if nbytes == 0:
             raise ValueError("bad batch/shape for dcx_pipeline_workspace_bytes")
-        ws = _ws.get("pipe", dev, nbytes)
+        if ws is None:
+            ws = det._ws.get("pipe", dev, nbytes)
+        elif ws.device != dev or ws.dtype != torch.uint8 or not ws.is_contiguous() or ws.numel() < nbytes:
+            raise ValueError(f"ws must be a contiguous uint8 tensor of >= {nbytes} bytes on {dev}")
         # outputs: counts [B] | rows [B,kmax,4] | xy [B,kmax,2], one allocation so one D2H moves all
         n_i32 = b + b * kmax * 4 + b * kmax * 2
-        if out is None or out.numel() != n_i32:
+        if out is None:
             out = torch.empty((n_i32,), dtype=torch.int32, device=dev)
+        elif out.device != dev or out.dtype != torch.int32 or out.numel() != n_i32 or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous int32 tensor of {n_i32} elements on {dev}")
         base = out.data_ptr()
         counts_p, rows_p, xy_p = base, base + 4 * b, base + 4 * (b + b * kmax * 4)
         _lib.check(L.dcx_infer_batch(det.handle, ref.handle if ref else None, frames.data_ptr(), h * w, w, b, h, w,

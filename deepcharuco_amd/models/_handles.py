@@ -33,13 +33,18 @@ def tensor_pointer_array(sd: StateDict, kind: str, n_ids: int):
 
 
 class Workspace:
-    """Grow-only device scratch buffer (a torch uint8 tensor) per device."""
+    """Grow-only device scratch buffers (torch uint8 tensors), one per (tag, device, HIP stream).
+
+    Owned by a model object, keyed by the stream that is current when it is requested: two streams (or two threads on
+    two streams) driving the same model never share activations, and a buffer is only ever used -- and, when it has to
+    grow, released -- on the stream it was allocated on, so torch's stream-ordered allocator keeps the old block alive
+    until the kernels already queued on that stream are done with it."""
 
     def __init__(self):
-        self._buf: Dict[Tuple[str, int], torch.Tensor] = {}
+        self._buf: Dict[Tuple[str, int, int], torch.Tensor] = {}
 
     def get(self, tag: str, device: torch.device, nbytes: int) -> torch.Tensor:
-        key = (tag, device.index)
+        key = (tag, device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = None
@@ -54,6 +59,8 @@ def check_dev_tensor(t: torch.Tensor, device: torch.device, dtype, name: str) ->
         raise TypeError(f"{name} must be a torch.Tensor")
     if t.device.type != "cuda":
         raise RuntimeError(f"{name} must live on the GPU (got {t.device}); deepcharuco_amd has no CPU path")
+    if device is not None and device.index is not None and t.device != device:
+        raise RuntimeError(f"{name} lives on {t.device} but the model's weights are on {device}")
     if t.dtype != dtype:
         t = t.to(dtype)
     return t.contiguous()

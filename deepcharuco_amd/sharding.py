@@ -52,6 +52,86 @@ def gather_packed(packed_local: torch.Tensor, group=None, async_op: bool = False
     return out, work
 
 
+class OverlappedGather:
+    """The path's exchange step, off the compute stream ("one HIP stream for compute + one for
+    comms", the collective overlapped with the next batch's conv work).
+
+    ``depth`` packed output buffers rotate: step i writes its corner lists into ``acquire(i)`` on the compute stream;
+    ``launch(i)`` makes the side stream wait for that step's completion event, issues ONE ``all_gather_into_tensor`` of
+    the fused buffer (RCCL over xGMI) with ``async_op=True`` and copies the gathered lists to pinned host memory -- all
+    on the side stream, so step i+1's convolutions run underneath.  A slot is handed out again only after the side
+    stream has finished reading it (an event the compute stream waits on; the host never blocks).
+    ``backend="gloo"`` (several ranks on ONE GPU, smoke tests) has no device collective: the side stream does the D2H
+    and the host-side gloo all-gather is completed lazily in ``retire`` / ``result`` -- after the next step has been
+    enqueued, so the GPU still overlaps it."""
+
+    def __init__(self, n_i32: int, device: torch.device, group=None, backend: str = "nccl", depth: int = 2):
+        self.n, self.dev, self.group, self.backend, self.depth = n_i32, device, group, backend, depth
+        self.world = dist.get_world_size(group)
+        self.overlapped = True
+        with torch.cuda.device(device):
+            self.side = torch.cuda.Stream()
+            self.out = [torch.empty((n_i32,), dtype=torch.int32, device=device) for _ in range(depth)]
+            self.ev_compute = [torch.cuda.Event() for _ in range(depth)]
+            self.ev_side = [torch.cuda.Event() for _ in range(depth)]
+            self.host = [torch.empty((self.world, n_i32), dtype=torch.int32).pin_memory() for _ in range(depth)]
+            if backend == "nccl":
+                self.gathered = [torch.empty((self.world, n_i32), dtype=torch.int32, device=device) for _ in range(depth)]
+            else:
+                self.host_local = [torch.empty((n_i32,), dtype=torch.int32).pin_memory() for _ in range(depth)]
+        self._pending = [False] * depth          # gloo: D2H issued, host all-gather not yet done
+        self._used = [False] * depth
+
+    def acquire(self, i: int) -> torch.Tensor:
+        """Output buffer of step i; the compute stream waits until the side stream has released it."""
+        s = i % self.depth
+        if self._used[s]:
+            torch.cuda.current_stream(self.dev).wait_event(self.ev_side[s])
+        return self.out[s]
+
+    def launch(self, i: int) -> None:
+        """Call right after step i's kernels have been enqueued on the current (compute) stream."""
+        s = i % self.depth
+        compute = torch.cuda.current_stream(self.dev)
+        self.ev_compute[s].record(compute)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_compute[s])
+            if self.backend == "nccl":
+                work = dist.all_gather_into_tensor(self.gathered[s].view(-1), self.out[s], group=self.group, async_op=True)
+                work.wait()                                   # the SIDE stream waits for RCCL's stream; the host does not
+                self.host[s].copy_(self.gathered[s], non_blocking=True)
+            else:
+                self.host_local[s].copy_(self.out[s], non_blocking=True)
+                self._pending[s] = True
+            self.ev_side[s].record(self.side)
+        self._used[s] = True
+
+    def retire(self, i: int) -> None:
+        """gloo only: complete step i's host-side all-gather (no-op for nccl, for i < 0 and when already done)."""
+        if i < 0:
+            return
+        s = i % self.depth
+        if self._pending[s]:
+            self.ev_side[s].synchronize()
+            dist.all_gather_into_tensor(self.host[s].view(-1), self.host_local[s], group=self.group)
+            self._pending[s] = False
+
+    def drain(self) -> None:
+        for s in range(self.depth):
+            if self._pending[s]:
+                self.ev_side[s].synchronize()
+                dist.all_gather_into_tensor(self.host[s].view(-1), self.host_local[s], group=self.group)
+                self._pending[s] = False
+        self.side.synchronize()
+
+    def result(self, i: int) -> np.ndarray:
+        """(world, n) int32 host array of step i's gathered corner lists (blocks until they have arrived)."""
+        s = i % self.depth
+        self.retire(i)
+        self.ev_side[s].synchronize()
+        return self.host[s].numpy().copy()
+
+
 def unpack_gathered(gathered: np.ndarray, n_frames: int, world: int, kmax: int, refined: bool):
     """Host side: (R, len) gathered buffers -> list of n_frames keypoint arrays in global frame order."""
     batch_max = shard_range(n_frames, 0, world)[1]
@@ -89,12 +169,62 @@ def infer_frames_sharded(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refi
         packed = run_local(frames_gray[lo:hi])
     else:
         packed = None
+    host_exchange = dist.get_backend(group) == "gloo"        # gloo (CPU tests, several ranks on one GPU): through host memory
     if packed is None:
-        dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+        dev = "cpu" if host_exchange else torch.device("cuda", torch.cuda.current_device())
         packed = torch.zeros(packed_len(0, kmax), dtype=torch.int32, device=dev)
+    elif host_exchange and packed.device.type != "cpu":
+        packed = packed.cpu()
     packed = pad_packed(packed, hi - lo, kmax, batch_max)
     gathered, _ = gather_packed(packed, group)
     res, counts = unpack_gathered(gathered.cpu().numpy(), n, world, kmax, refinenet is not None)
+    if int(counts.max(initial=0)) > kmax:
+        raise RuntimeError(f"a frame fired {int(counts.max())} cells > kmax={kmax}; raise kmax")
+    return res
+
+
+def infer_batches_sharded(batches, dust_bin_ids: int, deepc, refinenet=None, kmax: int = 64, group=None,
+                          backend: Optional[str] = None, depth: int = 2):
+    """Pipelined collective caller: ``batches`` is an iterable of (B,H,W) uint8 host arrays of ONE shape (every rank
+    passes the same sequence); yields, in order, the list of B keypoint arrays of each batch on every rank.
+
+    Batch i+1's upload and kernels are enqueued before batch i's gathered corner lists are waited for, and the gather
+    itself runs on :class:`OverlappedGather`'s side stream, so the exchange step costs no GPU time on the compute
+    stream.  Ranks with fewer frames than rank 0 (ragged split) pad with blank frames whose results are dropped."""
+    from .inference import infer_batch_device  # local import: needs the GPU library
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    backend = backend or dist.get_backend(group)
+    det = deepc.model if hasattr(deepc, "model") else deepc
+    dev = det.device
+    og = None
+    pending = []          # (step index, n_frames)
+    i = 0
+    for frames in batches:
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, h, w = frames.shape
+        lo, hi = shard_range(n, rank, world)
+        bmax = shard_range(n, 0, world)[1]
+        if og is None:
+            shape0 = (n, h, w)
+            og = OverlappedGather(packed_len(bmax, kmax), dev, group, backend, depth)
+        elif (n, h, w) != shape0:
+            raise ValueError("infer_batches_sharded needs batches of one shape; flush and start a new call")
+        local = np.zeros((bmax, h, w), np.uint8)
+        local[:hi - lo] = frames[lo:hi]
+        if len(pending) == depth:                       # the slot about to be reused: hand its results out first
+            j, nj = pending.pop(0)
+            yield _unpack_step(og, j, nj, world, kmax, refinenet is not None)
+        d = torch.from_numpy(local).to(dev, non_blocking=True)
+        infer_batch_device(d, dust_bin_ids, deepc, refinenet, kmax, out=og.acquire(i))
+        og.launch(i)
+        pending.append((i, n))
+        i += 1
+    for j, nj in pending:
+        yield _unpack_step(og, j, nj, world, kmax, refinenet is not None)
+
+
+def _unpack_step(og: "OverlappedGather", step: int, n_frames: int, world: int, kmax: int, refined: bool):
+    res, counts = unpack_gathered(og.result(step), n_frames, world, kmax, refined)
     if int(counts.max(initial=0)) > kmax:
         raise RuntimeError(f"a frame fired {int(counts.max())} cells > kmax={kmax}; raise kmax")
     return res

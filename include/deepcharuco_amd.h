@@ -32,7 +32,7 @@ extern "C" {
 #define DCX_E_ARG      (-1)   /* null pointer / bad scalar */
 #define DCX_E_SHAPE    (-2)   /* H or W not a multiple of 8, patch not 24x24 ... */
 #define DCX_E_WS       (-3)   /* workspace too small */
-#define DCX_E_NIDS     (-4)   /* dust_bin / n_ids mismatch */
+#define DCX_E_NIDS     (-4)   /* n_ids outside [1, 62] at create(); dust_bin outside [0, 255] at decode */
 
 typedef struct dcx_detector dcx_detector;   /* dcModel  (models/net.py:9-99)        */
 typedef struct dcx_refiner  dcx_refiner;    /* RefineNet (models/refinenet.py:9-115) */
@@ -81,6 +81,8 @@ int dcx_detector_forward(const dcx_detector* det,
  * where loc == 64; cells with id != dust_bin emit a row {x = 8*cx + loc%8, y = 8*cy + loc/8,
  * id, cell = cy*Wc + cx} in raster order per frame.  d_counts[b] = number of firing cells
  * (may exceed kmax; only the first kmax rows are stored).  d_rows: int32 [B][kmax][4].
+ * dust_bin is the reference's `dust_bin_ids` argument: any value in [0, 255] (else DCX_E_NIDS) with the reference's
+ * semantics `ids != dust_bin_ids` -- it normally equals n_ids but is not required to.
  * Optional dense maps d_loc_argmax / d_ids_argmax: int32 [B][Hc][Wc] (ids map is post-mask).
  * dcx_detector_decode reads the logits the preceding dcx_detector_forward left in d_ws and
  * uses 4 bytes per cell of scratch in it (arg-max of all cells in parallel, then one ordered

@@ -78,6 +78,64 @@ def import_reference():
     return ref_inf, ref_net, ref_rn, ref_mu
 
 
+def metrics_golden(outdir):
+    """Accuracy-harness fixture: the REFERENCE's DC_Metrics / Refinenet_Metrics (models/metrics.py:38-161, torchmetrics
+    stubbed) and utils.pixel_error (utils.py:33-52) on the seeded cases of oracle/metrics_cases.py.  The product
+    restatement (deepcharuco_amd/metrics.py) is asserted equal here through its key-point entry (the logits entry
+    needs the GPU decode and is compared with these values by the -m gpu test)."""
+    import contextlib
+    import io
+    from models import metrics as ref_metrics   # noqa  (sys.path / cwd set by import_reference)
+    import utils as ref_utils                   # noqa
+    from oracle import metrics_cases as MC
+    from deepcharuco_amd import metrics as PM
+
+    fx = {}
+    ref_dc, my_dc = ref_metrics.DC_Metrics(16), PM.DC_Metrics(16)
+    per_update = []
+    for seed in (11, 12):
+        loc, ids, loc_t, ids_t = [torch.from_numpy(a) for a in MC.dc_case(seed)]
+        ref_dc.update((loc, ids), (loc_t, ids_t))
+        per_update.append([float(ref_dc.distance), float(ref_dc.ratio)])
+        # product harness fed with the key-points the oracle decodes from the same logits
+        res = []
+        for b in range(loc.shape[0]):
+            k, i = O.pred_to_keypoints(loc[b:b + 1], ids[b:b + 1], 16)
+            res.append(np.concatenate([k.numpy(), i.numpy()[:, None]], axis=1) if k.shape[0] else np.array([]))
+        my_dc.update_keypoints(res, (loc_t, ids_t))
+        assert float(my_dc.distance) == float(ref_dc.distance) and float(my_dc.ratio) == float(ref_dc.ratio), seed
+    d, r = ref_dc.compute()
+    fx["dc_seeds"] = np.array([11, 12])
+    fx["dc_per_update"] = np.array(per_update, np.float64)
+    fx["dc_distance"], fx["dc_ratio"] = np.float64(d), np.float64(r)
+    assert 0.0 < float(r) < 2.0 and float(d) > 0.0
+
+    ref_rn = ref_metrics.Refinenet_Metrics()
+    rn_updates = []
+    for seed in (21, 22):
+        heat, target = [torch.from_numpy(a) for a in MC.refinenet_case(seed)]
+        ref_rn.update(heat, target)
+        rn_updates.append(float(ref_rn.distance))
+    fx["rn_seeds"] = np.array([21, 22])
+    fx["rn_per_update"] = np.array(rn_updates, np.float64)
+    fx["rn_distance"] = np.float64(ref_rn.compute())
+
+    raw, ref, tgt, bad = MC.pixel_error_case(31)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e_raw, e_ref = ref_utils.pixel_error(raw, ref, tgt)
+        none_case = ref_utils.pixel_error(bad, ref, tgt)
+        m_raw, m_ref = PM.pixel_error(raw, ref, tgt)
+    assert none_case == (None, None) and PM.pixel_error(bad, ref, tgt, verbose=False) == (None, None)
+    assert (m_raw, m_ref) == (e_raw, e_ref)
+    fx["pe_seed"] = np.array(31)
+    fx["pe_raw"], fx["pe_ref"] = np.float64(e_raw), np.float64(e_ref)
+    fx["pe_l2"] = ref_utils.compute_l2_distance(raw[:, :2], raw[:, 2], tgt[:, :2], tgt[:, 2])
+    assert np.array_equal(fx["pe_l2"], PM.compute_l2_distance(raw[:, :2], raw[:, 2], tgt[:, :2], tgt[:, 2]))
+    np.savez_compressed(os.path.join(outdir, "metrics_golden.npz"), **fx)
+    print(f"[golden] metrics: DC distance {float(d):.6f} ratio {float(r):.6f}; RefineNet distance {float(fx['rn_distance']):.6f}; "
+          f"pixel_error raw {e_raw:.6f} ref {e_ref:.6f}; product harness == reference")
+
+
 def ref_models(ref_net, ref_rn, sd_dc, sd_rn, n_ids):
     dc = ref_net.lModel(ref_net.dcModel(n_ids))
     missing = dc.model.load_state_dict(O.to_torch_state_dict(sd_dc), strict=False)
@@ -112,6 +170,8 @@ CASES = [
     dict(name="noise_240x320", wseed=1234, kind="noise", fseed=0, H=240, W=320, K=16, full=True),
     dict(name="board_240x320", wseed=1234, kind="board", fseed=1, H=240, W=320, K=16, full=False),
     dict(name="board_480x640", wseed=7, kind="board", fseed=2, H=480, W=640, K=16, full=False),
+    # BASELINE configs[4] resolution; K forced to exactly 16 by the top-16 non-dust-bin margins (calibrate_dustbin)
+    dict(name="board4_960x1280", wseed=91, kind="board4", fseed=900, H=960, W=1280, K=16, full=False),
 ]
 N_IDS = 16
 
@@ -233,6 +293,8 @@ def main():
     kp = np.array([[10.5, 20.25, 3], [100.0, 50.0, 0], [30.0, 31.0, 15], [7.0, 8.0, 9]])
     objp, imgp = O.solve_pnp_object_points(kp, 5, 5, 0.01)
     np.savez_compressed(os.path.join(outdir, "solve_pnp_points.npz"), kp=kp, objp=objp, imgp=imgp)
+
+    metrics_golden(outdir)
 
     with open(os.path.join(outdir, "index.json"), "w") as f:
         json.dump(index, f, indent=1)

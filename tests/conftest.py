@@ -10,7 +10,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
-CASES = ["tiny_noise_64x96", "noise_240x320", "board_240x320", "board_480x640"]
+CASES = ["tiny_noise_64x96", "noise_240x320", "board_240x320", "board_480x640", "board4_960x1280"]
 
 
 def pytest_configure(config):

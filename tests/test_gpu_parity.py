@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_ATOL = 5e-5     # |logit| <= ~6
 XY_ATOL = 1e-4        # px, north-star tolerance (we get exact equality)
-MARGIN = 1e-4         # arg-max must match exactly wherever the reference's top-2 gap exceeds this
+MARGIN = 1e-5         # arg-max must match exactly wherever the reference's top-2 gap exceeds this (SURVEY.md H1 policy);
+                      # cells below it are COUNTED and their agreement reported in gpurun_out/parity_report.json
 
 REPORT = {}
 
@@ -310,7 +311,10 @@ def test_detector_logits_and_argmax_vs_golden(dev, golden):
     safe_loc = fx["loc_margin"] > MARGIN
     near = int((~safe_loc).sum())
     mism_all = int((la != fx["loc_argmax"]).sum())
-    _report(f"detector_argmax/{golden.name}", dict(cells=int(la.size), near_tie_cells=near, loc_mismatch_total=mism_all))
+    near_ids = int((~(fx["ids_margin"] > MARGIN)).sum())
+    _report(f"detector_argmax/{golden.name}", dict(cells=int(la.size), margin=MARGIN, near_tie_cells_loc=near, near_tie_cells_ids=near_ids,
+                                                   loc_mismatch_total=mism_all,
+                                                   ids_mismatch_total=int((ia != fx["ids_argmax"]).sum())))
     assert np.array_equal(la[safe_loc], fx["loc_argmax"].astype(np.int64)[safe_loc])
     safe = safe_loc & (fx["ids_margin"] > MARGIN)
     assert np.array_equal(ia[safe], fx["ids_argmax"].astype(np.int64)[safe])
@@ -498,6 +502,158 @@ def test_config5_resolution_1280x960(dev):
         assert res[b].shape == exp.shape and np.array_equal(res[b], exp), f"frame {b}"
 
 
+def test_config5_bs32_1280x960_fixed_k16(dev):
+    """BASELINE configs[4] at its per-GPU size: 32 frames of 1280x960 with EXACTLY 16 corners in every frame (frames
+    selected by the workload generator, deepcharuco_amd/workload.py), kmax = 16 -> 512 RefineNet patches.  Four frames are
+    checked against the live oracle; the committed reference output at this resolution (tests/golden/board4_960x1280.npz,
+    K forced to 16 by top-16 margin selection) is checked by the golden-parametrised tests above."""
+    from deepcharuco_amd import workload as WL
+    from deepcharuco_amd.inference import infer_batch_device, unpack_results
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    calib = torch.from_numpy(W.synthetic_frames("board4", 20000, 32, 960, 1280)).to(dev)
+    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 91), calib, dev, per_frame=16)
+    del calib
+    sd_rn = W.synthetic_state_dict("refinenet", 92)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    frames, kept = WL.select_fixed_k_frames("board4", 20000, 32, 960, 1280, 16, dc, dev)
+    assert frames.shape == (32, 960, 1280) and len(set(kept)) == 32
+    d = torch.from_numpy(frames).to(dev)
+    packed = infer_batch_device(d, 16, dc, rn, kmax=16).cpu().numpy()
+    res, counts = unpack_results(packed, 32, 16, True)
+    assert counts.tolist() == [16] * 32                                   # fixed K: every frame fires exactly 16 cells
+    assert all(r.shape == (16, 3) and r.dtype == np.float64 for r in res)
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    corners = 0
+    for b in (0, 1, 17, 31):
+        exp = O.infer_image(None, 16, t_dc, t_rn, gray=frames[b])
+        assert res[b].shape == exp.shape and np.array_equal(res[b], exp), f"frame {b}"
+        corners += exp.shape[0]
+    again = unpack_results(infer_batch_device(d, 16, dc, rn, kmax=16).cpu().numpy(), 32, 16, True)[0]
+    assert all(np.array_equal(a, b) for a, b in zip(res, again))
+    _report("config5_bs32_1280x960", dict(frames=32, corners_per_frame=16, frames_checked=4, corners_checked=corners,
+                                          candidates_drawn=int(max(kept)) + 1))
+
+
+def test_dust_bin_semantics_and_validation(dev):
+    """dust_bin is the reference's free `dust_bin_ids` argument (model_utils.py:76,111): any value in [0, 255] must give
+    `ids != dust_bin` semantics (also when it is NOT n_ids); anything else is DCX_E_NIDS, never silently different."""
+    from deepcharuco_amd import _lib
+    from deepcharuco_amd.models.model_utils import pred_argmax, pred_to_keypoints
+    g = torch.Generator().manual_seed(9)
+    loc = torch.randn(2, 65, 6, 8, generator=g)
+    ids = torch.randn(2, 17, 6, 8, generator=g)
+    loc[0, 64, 2, 3] = 30.0
+    for db in (16, 5, 0, 200):
+        la, ia = pred_argmax(loc.to(dev), ids.to(dev), db)
+        ola, oia = O.pred_argmax(loc, ids, db)
+        assert torch.equal(la.cpu(), ola) and torch.equal(ia.cpu(), oia), db
+        k, i = pred_to_keypoints(loc.to(dev), ids.to(dev), db)
+        ok, oi = O.pred_to_keypoints(loc, ids, db)
+        assert torch.equal(k.cpu(), ok) and torch.equal(i.cpu(), oi), db
+    for db in (-1, 256, 1 << 20):
+        with pytest.raises(_lib.DcxError, match="DCX_E_NIDS"):
+            pred_to_keypoints(loc.to(dev), ids.to(dev), db)
+
+
+def test_argument_validation_python_layer(dev, golden_tiny):
+    """wrong-shaped / wrong-dtype `out` and foreign-device tensors raise instead of being silently replaced."""
+    from deepcharuco_amd.inference import infer_batch_device
+    dc, rn = _models(golden_tiny, dev)
+    fr = torch.from_numpy(golden_tiny.frame[None]).to(dev)
+    with pytest.raises(ValueError):
+        infer_batch_device(fr, 16, dc, rn, kmax=8, out=torch.empty(5, dtype=torch.int32, device=dev))
+    with pytest.raises(ValueError):
+        infer_batch_device(fr, 16, dc, rn, kmax=8, out=torch.empty(1 + 8 * 6, dtype=torch.float32, device=dev))
+    with pytest.raises(ValueError):
+        infer_batch_device(fr, 16, dc, rn, kmax=8, ws=torch.empty(16, dtype=torch.uint8, device=dev))
+    with pytest.raises(ValueError):
+        infer_batch_device(fr.cpu(), 16, dc, rn, kmax=8)
+    out = torch.empty(1 + 8 * 6, dtype=torch.int32, device=dev)
+    assert infer_batch_device(fr, 16, dc, rn, kmax=8, out=out).data_ptr() == out.data_ptr()
+    with pytest.raises(RuntimeError):
+        dc.model.forward(torch.zeros((1, 1, 64, 96)))               # CPU tensor: no CPU path
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(RuntimeError, match="weights are on"):
+            dc.model.forward(torch.zeros((1, 1, 64, 96), device="cuda:1"))
+
+
+def test_two_streams_share_one_model_pair(dev):
+    """the pipeline scratch is owned by the detector and keyed by the current stream, so two
+    streams driving ONE model pair concurrently do not corrupt each other (they used to share a module-global buffer)."""
+    from deepcharuco_amd.inference import infer_batch_device, unpack_results
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 8100, 16, 240, 320)
+    sd_dc = _calibrated(31, frames[:4], target_per_frame=14)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 32), dev))
+    d = torch.from_numpy(frames).to(dev)
+    ref = [infer_batch_device(d[i * 8:(i + 1) * 8], 16, dc, rn, 64).cpu().numpy().copy() for i in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(10):
+        outs = [None, None]
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i] = infer_batch_device(d[i * 8:(i + 1) * 8], 16, dc, rn, 64)
+        torch.cuda.synchronize()
+        for i in range(2):
+            a = unpack_results(outs[i].cpu().numpy(), 8, 64, True)[0]
+            b = unpack_results(ref[i], 8, 64, True)[0]
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rep, i)
+
+
+def test_hazard_soak_repeated_runs_are_bit_identical(dev):
+    """The MFMA kernels pad their own hazards around inline asm (dcx_conv_wino2.h): 60 repeated bs=32 runs plus three
+    other batch sizes must reproduce one SHA-256 per batch size (packed corner lists of every frame), and the heat-map
+    / logits entry points must be bit-stable over 20 runs."""
+    import hashlib
+    from deepcharuco_amd.inference import infer_batch_device, unpack_results
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = np.concatenate([W.synthetic_frames("board", 9000, 48, 240, 320), W.synthetic_frames("noise", 9100, 16, 240, 320)])
+    sd_dc = _calibrated(1234, frames[::8], target_per_frame=16)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
+    d = torch.from_numpy(frames).to(dev)
+
+    def sha(b):
+        packed = infer_batch_device(d[:b], 16, dc, rn, 64).cpu().numpy()
+        res, counts = unpack_results(packed, b, 64, True)
+        h = hashlib.sha256(counts.tobytes())
+        for r in res:
+            h.update(np.ascontiguousarray(r).tobytes())
+        return h.hexdigest(), int(np.minimum(counts, 64).sum())
+    report = {}
+    for b, reps in ((32, 60), (1, 20), (7, 20), (64, 20)):
+        first, corners = sha(b)
+        distinct = {first} | {sha(b)[0] for _ in range(reps - 1)}
+        report[f"bs{b}"] = dict(runs=reps, corners=corners, distinct_results=len(distinct))
+        assert len(distinct) == 1, f"bs={b}: {len(distinct)} different results in {reps} runs"
+    x = torch.from_numpy(np.stack([O.pre_bgr_image(f) for f in frames[:32]])).to(dev)
+    l0 = dc.model.forward(x)
+    for _ in range(20):
+        l1 = dc.model.forward(x)
+        assert torch.equal(l0["loc"], l1["loc"]) and torch.equal(l0["ids"], l1["ids"])
+    _report("hazard_soak", report)
+
+
+def test_colour_bgr_input_through_the_gpu_path(dev, golden_tiny):
+    """A real colour image (the fixtures replicate gray x3): infer_image converts with bgr2gray and must equal the oracle
+    fed with the oracle's own bgr2gray; when OpenCV is importable the formula is also checked against cv2 itself."""
+    from deepcharuco_amd.inference import infer_image
+    from deepcharuco_amd.imgproc import bgr2gray
+    dc, rn = _models(golden_tiny, dev)
+    rng = np.random.default_rng(77)
+    base = W.synthetic_frames("noise", 5, 1, 64, 96)[0].astype(np.int16)
+    bgr = np.clip(np.stack([base + rng.integers(-40, 41, base.shape), base + rng.integers(-8, 9, base.shape),
+                            base + rng.integers(-40, 41, base.shape)], axis=2), 0, 255).astype(np.uint8)
+    assert np.array_equal(bgr2gray(bgr), O.bgr2gray(bgr)) and not np.array_equal(O.bgr2gray(bgr), bgr[..., 1])
+    kp, img = infer_image(bgr, 16, dc, rn, device="cuda")
+    exp = O.infer_image(bgr, 16, O.to_torch_state_dict(golden_tiny.sd_dc), O.to_torch_state_dict(golden_tiny.sd_rn))
+    assert img is bgr and kp.shape == exp.shape and np.array_equal(kp, exp)
+    assert exp.ndim == 2 and exp.shape[0] > 0
+
+
 @pytest.mark.parametrize("n_ids", [8, 24])
 def test_other_board_sizes_n_ids(dev, n_ids):
     """n_ids = (rows-1)*(cols-1) is a model parameter (configs.py:34-35): 3x5 and 5x7 boards, not only 16."""
@@ -552,9 +708,9 @@ def test_c_abi_error_codes(dev, golden_tiny):
     assert rn.infer_patches(torch.zeros((0, 24, 24), device=dev), torch.zeros((0, 2), dtype=torch.int64, device=dev))[1].shape == (0, 2)
 
 
-def test_frame_stream_matches_infer_batch(dev):
-    """The double-buffered asynchronous caller returns, in order, exactly what infer_batch returns
-    (ragged last batch, more batches than slots)."""
+def test_frame_stream_matches_oracle(dev):
+    """The double-buffered asynchronous caller returns, in order, exactly what the ORACLE's per-frame infer_image
+    returns (ragged last batch, more batches than slots) -- and therefore what infer_batch returns."""
     from deepcharuco_amd.inference import infer_batch
     from deepcharuco_amd.stream import FrameStream
     from deepcharuco_amd.models.net import dcModel, lModel
@@ -568,7 +724,11 @@ def test_frame_stream_matches_infer_batch(dev):
     out = list(fs.run(chunks))
     assert [t for t, _ in out] == list(range(6))
     flat = [a for _, res in out for a in res]
-    assert len(flat) == 22 and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, ref))
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(W.synthetic_state_dict("refinenet", 56))
+    exp = [O.infer_image(None, 16, t_dc, t_rn, gray=f) for f in frames]
+    assert len(flat) == 22 and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, exp))
+    assert sum(e.shape[0] for e in exp if e.ndim == 2) > 100
+    assert all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, ref))
 
 
 def test_parity_128_frames_every_corner(dev):

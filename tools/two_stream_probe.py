@@ -7,23 +7,19 @@ from deepcharuco_amd import _lib, weights as W
 from deepcharuco_amd.inference import infer_batch_device
 from deepcharuco_amd.models.net import dcModel, lModel
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
-from deepcharuco_amd.models._handles import Workspace
-import deepcharuco_amd.inference as I
 dev = torch.device("cuda", 0)
 frames = torch.from_numpy(W.synthetic_frames("board", 1000, 64, 240, 320)).to(dev)
 sd = W.synthetic_state_dict("detector", 1234); sd["convDb.bias"][16] += np.float32(3.75)
 sd_rn = W.synthetic_state_dict("refinenet", 1235)
-# one model pair (= one set of handles + workspaces) per stream: handles are not shared across streams
+# one model pair per stream (the pipeline workspace is owned by the detector object and keyed by the current stream)
 pairs = [(lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(sd_rn, dev))) for _ in range(2)]
 
 def run(nstreams, B, steps=20):
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
-    wss = [Workspace() for _ in range(nstreams)]
     outs = [None] * nstreams
     def one():
         for s in range(nstreams):
             with torch.cuda.stream(streams[s]):
-                I._ws = wss[s]                     # separate pipeline workspace per stream
                 outs[s] = infer_batch_device(frames[s * B:(s + 1) * B], 16, pairs[s][0], pairs[s][1], 64, out=outs[s])
     for _ in range(3): one()
     torch.cuda.synchronize()
