@@ -22,7 +22,7 @@ from .models.net import dcModel, lModel
 from .models.refinenet import RefineNet, lRefineNet
 
 __all__ = ["load_models", "infer_image", "infer_image_staged", "infer_batch", "infer_batch_device",
-           "solve_pnp", "InferenceModel"]
+           "solve_pnp", "solve_pnp_batch", "solve_pnp_submit", "InferenceModel"]
 
 DEFAULT_KMAX = 64
 
@@ -40,21 +40,71 @@ def load_models(deepc_ckpt: str, refinenet_ckpt: Optional[str] = None, n_ids: in
     return deepc, refinenet
 
 
-def solve_pnp(keypoints, col_count, row_count, square_len, camera_matrix, dist_coeffs):
-    """inference.py:15-29. Host side (cv2.solvePnP), as in the reference."""
-    if keypoints.shape[0] < 4:
-        return False, None, None
+def _cv2_solvepnp():
+    try:
+        import cv2  # type: ignore
+    except ImportError as e:  # pragma: no cover - cv2 is absent in the build image
+        raise ImportError("solve_pnp needs OpenCV (cv2.solvePnP), which is not installed") from e
+    return cv2.solvePnP
+
+
+def _pnp_points(keypoints, col_count, row_count, square_len):
+    """inference.py:20-26: board-frame object points of the detected ids + their image points."""
     inn_rc = np.arange(1, row_count)
     inn_cc = np.arange(1, col_count)
     object_points = np.zeros(((col_count - 1) * (row_count - 1), 3), np.float32)
     object_points[:, :2] = np.array(np.meshgrid(inn_rc, inn_cc)).reshape((2, -1)).T * square_len
     image_points = keypoints[:, :2].astype(np.float32)
-    object_points_found = object_points[keypoints[:, 2].astype(int)]
-    try:
-        import cv2  # type: ignore
-    except ImportError as e:  # pragma: no cover - cv2 is absent in the build image
-        raise ImportError("solve_pnp needs OpenCV (cv2.solvePnP), which is not installed") from e
-    return cv2.solvePnP(object_points_found, image_points, camera_matrix, dist_coeffs)
+    return object_points[keypoints[:, 2].astype(int)], image_points
+
+
+def solve_pnp(keypoints, col_count, row_count, square_len, camera_matrix, dist_coeffs):
+    """inference.py:15-29. Host side (cv2.solvePnP), as in the reference."""
+    if keypoints.shape[0] < 4:
+        return False, None, None
+    object_points_found, image_points = _pnp_points(keypoints, col_count, row_count, square_len)
+    return _cv2_solvepnp()(object_points_found, image_points, camera_matrix, dist_coeffs)
+
+
+_pnp_pool = None
+
+
+def _pool(workers: Optional[int]):
+    """One process-wide thread pool for the PnP stage (cv2 releases the GIL inside solvePnP)."""
+    global _pnp_pool
+    import concurrent.futures as cf
+    import os
+    if _pnp_pool is None or (workers is not None and workers != _pnp_pool._max_workers):
+        _pnp_pool = cf.ThreadPoolExecutor(max_workers=workers or min(32, os.cpu_count() or 1), thread_name_prefix="dcx-pnp")
+    return _pnp_pool
+
+
+def solve_pnp_submit(keypoints_list, col_count, row_count, square_len, camera_matrix, dist_coeffs, workers: Optional[int] = None):
+    """Asynchronous half of :func:`solve_pnp_batch`: one future per frame (frames with < 4 corners resolve immediately
+    to ``(False, None, None)`` like inference.py:16-17).  Raises ImportError at once when OpenCV is missing."""
+    import concurrent.futures as cf
+    fn = _cv2_solvepnp()
+    pool = _pool(workers)
+    futs = []
+    for kp in keypoints_list:
+        kp = np.asarray(kp)
+        if kp.ndim != 2 or kp.shape[0] < 4:
+            f = cf.Future()
+            f.set_result((False, None, None))
+        else:
+            obj, img = _pnp_points(kp, col_count, row_count, square_len)
+            f = pool.submit(fn, obj, img, camera_matrix, dist_coeffs)
+        futs.append(f)
+    return futs
+
+
+def solve_pnp_batch(keypoints_list, col_count, row_count, square_len, camera_matrix, dist_coeffs, workers: Optional[int] = None):
+    """``solve_pnp`` (inference.py:15-29) for every frame of an ``infer_batch`` result, on host threads, so that the
+    one-call-per-frame host stage of the reference's callers (pose_estimation.py:58-63) does not cap a multi-GPU batch
+    path: at 8 k frames/s per GPU a serial ~50 us solvePnP per frame would already eat 40 % of one core per GPU.
+    Returns a list of ``(ret, rvec, tvec)`` in frame order, each identical to ``solve_pnp`` on that frame."""
+    return [f.result() for f in solve_pnp_submit(keypoints_list, col_count, row_count, square_len, camera_matrix,
+                                                dist_coeffs, workers)]
 
 
 # ------------------------------------------------------------------------------------------------

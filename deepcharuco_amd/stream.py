@@ -5,7 +5,10 @@ The reference's callers feed one frame at a time and block on every stage
 ``depth`` batches in flight: while batch i runs the HIP pipeline on the compute stream, batch i+1 is
 copied host->device from pinned memory on a copy stream and batch i-1's packed corner list is
 copied back; the host only ever waits on the oldest batch's completion event.  Results are the same
-arrays ``infer_batch`` returns (frames are independent).
+arrays ``infer_batch`` returns (frames are independent).  With ``pnp=dict(col_count=, row_count=, square_len=,
+camera_matrix=, dist_coeffs=)`` the pipeline gets the reference callers' last stage too (pose_estimation.py:61-63):
+when a batch is retired its frames' ``solve_pnp`` calls are submitted to host threads and run while the GPU works on
+the next batches; ``run`` then yields ``(ticket, results, poses)``.
 """
 from __future__ import annotations
 
@@ -14,17 +17,18 @@ from typing import Iterable, Iterator, List, Optional, Tuple
 import numpy as np
 import torch
 
-from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, unpack_results
+from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, solve_pnp_submit, unpack_results
 from .sharding import packed_len
 
 
 class FrameStream:
     def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 32, height: int = 240,
-                 width: int = 320, kmax: int = DEFAULT_KMAX, depth: int = 2):
+                 width: int = 320, kmax: int = DEFAULT_KMAX, depth: int = 2, pnp: Optional[dict] = None):
         det = deepc.model if hasattr(deepc, "model") else deepc
         self.dev = det.device
         self.dust_bin_ids, self.deepc, self.refinenet = dust_bin_ids, deepc, refinenet
         self.batch, self.h, self.w, self.kmax, self.depth = batch, height, width, kmax, depth
+        self.pnp = pnp
         n_out = packed_len(batch, kmax)
         with torch.cuda.device(self.dev):
             self.copy_stream = torch.cuda.Stream()
@@ -46,11 +50,13 @@ class FrameStream:
         res = res[:n]
         if n and int(counts[:n].max()) > self.kmax:      # rare: a frame exceeded the capacity -> exact re-run
             res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, kmax=self.kmax)
+        if self.pnp is not None:     # host stage: futures now, resolved when the batch is handed out
+            return ticket, res, solve_pnp_submit(res, **self.pnp)
         return ticket, res
 
     def submit(self, frames_gray: np.ndarray):
-        """Enqueue one batch (n <= batch frames). Returns the (ticket, results) of the batch that had to be
-        retired to make room, or None."""
+        """Enqueue one batch (n <= batch frames). Returns the (ticket, results) of the batch that had to be retired to
+        make room, or None; with a PnP stage the tuple carries a third element, the per-frame ``solve_pnp`` futures."""
         n = frames_gray.shape[0]
         if n > self.batch or tuple(frames_gray.shape[1:]) != (self.h, self.w) or frames_gray.dtype != np.uint8:
             raise ValueError("frames must be (n<=batch, H, W) uint8")
@@ -75,15 +81,27 @@ class FrameStream:
         self._ticket += 1
         return retired
 
-    def flush(self) -> Iterator[Tuple[int, List[np.ndarray]]]:
+    @staticmethod
+    def _resolve(r):
+        return r if len(r) == 2 else (r[0], r[1], [f.result() for f in r[2]])
+
+    def flush(self) -> Iterator[Tuple]:
         order = sorted((p[0], s) for s, p in enumerate(self._pending) if p is not None)
         for _, slot in order:
-            yield self._collect(slot)
+            yield self._resolve(self._collect(slot))
 
-    def run(self, batches: Iterable[np.ndarray]) -> Iterator[Tuple[int, List[np.ndarray]]]:
-        """batches: iterable of (n,H,W) uint8 arrays -> (ticket, per-frame keypoint arrays) in submission order."""
+    def run(self, batches: Iterable[np.ndarray]) -> Iterator[Tuple]:
+        """batches: iterable of (n,H,W) uint8 arrays -> (ticket, per-frame keypoint arrays[, per-frame (ret, rvec, tvec)])
+        in submission order.  The PnP futures of a retired batch are resolved one submission later, so they run on the
+        host threads while the next batch is being staged and the GPU is busy."""
+        held = None
         for fr in batches:
             r = self.submit(fr)
+            if held is not None:
+                yield self._resolve(held)
+                held = None
             if r is not None:
-                yield r
+                held = r
+        if held is not None:
+            yield self._resolve(held)
         yield from self.flush()

@@ -731,6 +731,44 @@ def test_frame_stream_matches_oracle(dev):
     assert all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, ref))
 
 
+def test_frame_stream_with_pnp_stage(dev, monkeypatch):
+    """FrameStream's last stage (pose_estimation.py:61-63): per-frame solve_pnp on host threads while the GPU works on the
+    next batch.  cv2 is absent here, so a recording stand-in for cv2.solvePnP checks WHAT is handed to it: the image points
+    must be the oracle's refined corners of that frame, in id order."""
+    import sys
+    import types
+    from deepcharuco_amd.stream import FrameStream
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+
+    def solvePnP(obj, img, cam, dist):
+        return True, img.copy(), obj.copy()
+    monkeypatch.setitem(sys.modules, "cv2", types.SimpleNamespace(solvePnP=solvePnP))
+    frames = W.synthetic_frames("board", 700, 10, 120, 160)
+    sd_dc = _calibrated(55, frames[:4])
+    sd_rn = W.synthetic_state_dict("refinenet", 56)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    pnp = dict(col_count=5, row_count=5, square_len=0.01, camera_matrix=np.eye(3), dist_coeffs=np.zeros(5))
+    fs = FrameStream(16, dc, rn, batch=4, height=120, width=160, kmax=64, depth=2, pnp=pnp)
+    out = list(fs.run([frames[i:i + 4] for i in range(0, 10, 4)]))
+    assert [o[0] for o in out] == [0, 1, 2] and all(len(o) == 3 for o in out)
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    flat_res = [a for o in out for a in o[1]]
+    flat_pose = [p for o in out for p in o[2]]
+    assert len(flat_res) == len(flat_pose) == 10
+    solved = 0
+    for f, res, pose in zip(frames, flat_res, flat_pose):
+        exp = O.infer_image(None, 16, t_dc, t_rn, gray=f)
+        assert res.shape == exp.shape and np.array_equal(res, exp)
+        if exp.ndim == 2 and exp.shape[0] >= 4:
+            objp, imgp = O.solve_pnp_object_points(exp, 5, 5, 0.01)
+            assert pose[0] is True and np.array_equal(pose[1], imgp) and np.array_equal(pose[2], objp)
+            solved += 1
+        else:
+            assert pose == (False, None, None)
+    assert solved >= 5
+
+
 def test_parity_128_frames_every_corner(dev):
     """128 frames (noise + board, ragged corner counts) through the sync-free batch path vs the oracle, frame by
     frame: every corner id, cell-derived integer position and sub-pixel xy must be identical."""

@@ -6,7 +6,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import REPO
+from conftest import GOLDEN, REPO
 from deepcharuco_amd import weights as W
 
 
@@ -110,6 +110,61 @@ def test_bgr2gray_host():
 def test_solve_pnp_short_circuit():
     from deepcharuco_amd.inference import solve_pnp
     assert solve_pnp(np.zeros((3, 3)), 5, 5, 0.01, None, None) == (False, None, None)
+
+
+def test_solve_pnp_batch_on_host_threads_with_a_recording_backend(monkeypatch):
+    """cv2 is absent in this image, so the PnP stage is tested with a recording stand-in for cv2.solvePnP (a fake
+    backend, test-only): per-frame object/image points must equal the fixture written from the reference's own
+    construction (inference.py:15-26), frames with < 4 corners short-circuit, order is preserved, several threads run."""
+    import sys
+    import threading
+    import time
+    import types
+    from deepcharuco_amd import inference as I
+    d = np.load(os.path.join(GOLDEN, "solve_pnp_points.npz"))
+    calls, lock = [], threading.Lock()
+
+    def solvePnP(obj, img, cam, dist):
+        time.sleep(0.01)
+        with lock:
+            calls.append((threading.get_ident(), obj.copy(), img.copy()))
+        return True, obj.sum(0, keepdims=True).T.astype(np.float64), img.sum(0, keepdims=True).T.astype(np.float64)
+    monkeypatch.setitem(sys.modules, "cv2", types.SimpleNamespace(solvePnP=solvePnP))
+    kp = d["kp"]
+    frames = [kp, np.array([]), kp[:3], kp[::-1].copy()] + [kp] * 12
+    cam, dist = np.eye(3), np.zeros(5)
+    out = I.solve_pnp_batch(frames, 5, 5, 0.01, cam, dist, workers=4)
+    assert len(out) == 16
+    assert out[1] == (False, None, None) and out[2] == (False, None, None)            # inference.py:16-17
+    single = I.solve_pnp(kp, 5, 5, 0.01, cam, dist)
+    assert out[0][0] is True and np.array_equal(out[0][1], single[1]) and np.array_equal(out[0][2], single[2])
+    assert np.array_equal(out[3][2], d["imgp"][::-1].sum(0, keepdims=True).T.astype(np.float64))
+    first = [c for c in calls if np.array_equal(c[2], d["imgp"])][0]
+    assert np.array_equal(first[1], d["objp"]) and first[1].dtype == np.float32 and first[2].dtype == np.float32
+    assert len({c[0] for c in calls}) > 1                                               # really ran on several threads
+    futs = I.solve_pnp_submit(frames[:2], 5, 5, 0.01, cam, dist)
+    assert [f.result()[0] for f in futs] == [True, False]
+
+
+def test_solve_pnp_without_opencv_raises_clearly(monkeypatch):
+    import sys
+    from deepcharuco_amd import inference as I
+    monkeypatch.setitem(sys.modules, "cv2", None)               # import cv2 -> ImportError
+    kp = np.load(os.path.join(GOLDEN, "solve_pnp_points.npz"))["kp"]
+    with pytest.raises(ImportError, match="OpenCV"):
+        I.solve_pnp(kp, 5, 5, 0.01, np.eye(3), np.zeros(5))
+    with pytest.raises(ImportError, match="OpenCV"):
+        I.solve_pnp_batch([kp], 5, 5, 0.01, np.eye(3), np.zeros(5))
+
+
+def test_bgr2gray_formula_against_opencv_when_available():
+    """cv2.cvtColor is third-party and absent here ("parity unpinned" for that one step): wherever OpenCV IS importable
+    this test pins the fixed-point restatement against it on a random colour image."""
+    cv2 = pytest.importorskip("cv2")
+    from oracle import deepcharuco_oracle as O
+    rng = np.random.default_rng(5)
+    bgr = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    assert np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY), O.bgr2gray(bgr))
 
 
 def test_shard_range_partition():
