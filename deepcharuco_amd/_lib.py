@@ -70,6 +70,8 @@ SIGNATURES = {
     "dcx_set_timing": (_i, [_i]),
     "dcx_last_timings": (_i, [C.POINTER(C.c_float)]),
     "dcx_conv_pick_name": (C.c_char_p, [_i] * 8),
+    "dcx_set_deterministic": (_i, [_i]),
+    "dcx_get_deterministic": (_i, []),
     "dcx_profile_enable": (_i, [_i]),
     "dcx_profile_count": (_i, []),
     "dcx_profile_filter": (_i, [_i]),

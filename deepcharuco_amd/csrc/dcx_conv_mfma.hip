@@ -113,6 +113,17 @@ int dcx_inlane_pool_enabled() {
     return v;
 }
 
+// Deterministic mode (dcx_set_deterministic / DCX_DETERMINISTIC=1): every layer runs on the direct kernels, whose fp32
+// summation order per output element (chunk / tap / s / j, dcx_conv_mfma.h) does not depend on the tile, the batch size
+// or the CU count -- logits are then bit-identical for a frame alone and inside any batch, on any device.  Default off:
+// the cost model may pick a Winograd family for large launches, whose logits differ from the direct ones in the last
+// bits (each family is bit-exact against its own restatement; arg-max outputs agree except on exact near-ties).
+int g_deterministic = -1;
+int dcx_deterministic_enabled() {
+    if (g_deterministic < 0) { const char* e = getenv("DCX_DETERMINISTIC"); g_deterministic = (e && atoi(e)) ? 1 : 0; }
+    return g_deterministic;
+}
+
 int dcx_big_tiles_disabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("DCX_BIG_TILES"); v = (e && atoi(e)) ? 0 : 1; }   // opt-in: measured slower
@@ -142,8 +153,8 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         if (c.ks != ks || c.pool != pool || c.epi != epi) continue;
         if (cout_pad % c.cout_tile != 0) continue;
         if (c.inlane && !dcx_inlane_pool_enabled()) continue;
-        if (c.wino == 1 && !dcx_wino_enabled()) continue;
-        if (c.wino == 2 && !dcx_wino2_enabled()) continue;
+        if (c.wino == 1 && (!dcx_wino_enabled() || dcx_deterministic_enabled())) continue;
+        if (c.wino == 2 && (!dcx_wino2_enabled() || dcx_deterministic_enabled())) continue;
         if (c.group > 1 && (!allow_group || ho > c.th || wo > c.tw)) continue;   // grouped tiles: whole small maps only
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
         if (c.cap > 256 && (dcx_big_tiles_disabled() || (double)ho * wo / ((double)tiles * c.cap) < 0.999)) continue;
@@ -191,6 +202,9 @@ extern "C" const char* dcx_conv_pick_name(int n, int cin, int ho, int wo, int co
     const CfgEntry* c = pick(n, cin, ho, wo, dcx_conv_cout_pad(cout), ks, pool, epi);
     return c ? c->name : "";
 }
+
+extern "C" int dcx_set_deterministic(int enabled) { g_deterministic = enabled ? 1 : 0; return 0; }
+extern "C" int dcx_get_deterministic(void) { return dcx_deterministic_enabled(); }
 
 extern "C" int dcx_profile_enable(int enabled) {
     g_prof = enabled != 0;

@@ -22,7 +22,7 @@ from .models.net import dcModel, lModel
 from .models.refinenet import RefineNet, lRefineNet
 
 __all__ = ["load_models", "infer_image", "infer_image_staged", "infer_batch", "infer_batch_device",
-           "solve_pnp", "solve_pnp_batch", "solve_pnp_submit", "InferenceModel"]
+           "solve_pnp", "solve_pnp_batch", "solve_pnp_submit", "set_deterministic", "InferenceModel"]
 
 DEFAULT_KMAX = 64
 
@@ -109,6 +109,12 @@ def solve_pnp_batch(keypoints_list, col_count, row_count, square_len, camera_mat
 
 # ------------------------------------------------------------------------------------------------
 
+def set_deterministic(enabled: bool = True) -> None:
+    """Force the direct convolution kernels for every layer: logits become bit-identical across batch sizes and devices
+    (``dcx_set_deterministic``).  Process-global."""
+    _lib.check(_lib.lib().dcx_set_deterministic(1 if enabled else 0), "dcx_set_deterministic")
+
+
 def _unwrap(deepc, refinenet):
     det = deepc.model if hasattr(deepc, "model") else deepc
     ref = None
@@ -194,9 +200,12 @@ def unpack_results(packed: np.ndarray, batch: int, kmax: int, refined: bool) -> 
 def infer_batch(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX):
     """Batched infer_image: frames_gray (B,H,W) uint8 host array -> list of B keypoint arrays.
 
-    Frames are independent (the reference has no cross-frame state), so frame b's result equals
-    ``infer_image`` on that frame alone.  If a frame fires more than ``kmax`` cells the batch is
-    re-run with a larger capacity (never silently truncated).
+    Frames are independent (the reference has no cross-frame state): frame b's corners equal ``infer_image`` on that
+    frame alone wherever the arg-max decisions are not exact near-ties.  (The launcher may run a layer on a different
+    kernel family at B=32 than at B=1 -- direct vs Winograd -- so logits can differ in their last bits, <= ~1.5e-5;
+    a cell whose top-2 logits are closer than that may decode differently.  ``set_deterministic(True)`` pins one
+    summation order for every batch size at ~0.6x the throughput; see DESIGN.md "Numerics".)  If a frame fires more than
+    ``kmax`` cells the batch is re-run with a larger capacity (never silently truncated).
     """
     det, _ = _unwrap(deepc, refinenet)
     dev = det.device

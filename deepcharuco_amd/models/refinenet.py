@@ -71,6 +71,9 @@ class RefineNet:
         heat = torch.empty((k, 1, 64, 64), dtype=torch.float32, device=dev) if want_heat else None
         xy = table = None
         if keypoints is not None:   # corners_og = (corners - 32) / 8 + keypoints computed by the finalize kernel
+            if keypoints.dtype.is_floating_point or keypoints.dtype == torch.bool:
+                raise TypeError("keypoints must be an integer tensor (the detector's pixel coordinates, as "
+                                "pred_to_keypoints returns them); float keypoints would be truncated")
             xy = torch.empty((k, 2), dtype=torch.float32, device=dev)
             table = torch.zeros((k, 4), dtype=torch.int32, device=dev)
             table[:, 1:3] = keypoints.to(device=dev, dtype=torch.int32)

@@ -139,18 +139,31 @@ def validate_state_dict(sd: StateDict, kind: str, n_ids: int = 16) -> None:
                     raise ValueError(f"{kind}.{s.bn}.{t} has wrong shape")
 
 
-def state_dict_from_checkpoint(path: str, kind: str, n_ids: int = 16) -> StateDict:
+def state_dict_from_checkpoint(path: str, kind: str, n_ids: int = 16, allow_unsafe: Optional[bool] = None) -> StateDict:
     """Lightning-free reader for the reference's ``.ckpt`` files.
 
     ``lModel.load_from_checkpoint`` (inference.py:74,80) reads a ``torch.save``d
     dict whose ``state_dict`` keys are ``model.<layer>.<tensor>``; plain
     ``torch.save(module.state_dict())`` files (no prefix, no wrapper) load too.
     ``num_batches_tracked`` and the torchmetrics states are ignored.
+
+    The file is read with ``weights_only=True`` (tensors and plain containers only).  A checkpoint that pickles other
+    objects (e.g. hyper-parameters holding custom classes) is refused unless the caller opts in with
+    ``allow_unsafe=True`` or ``DCX_ALLOW_UNSAFE_CKPT=1`` -- a full unpickle executes code from the file, so it is never
+    the silent fallback; a missing or truncated file raises its own error and is not retried.
     """
+    import os
+    import pickle
     import torch
+    if allow_unsafe is None:
+        allow_unsafe = os.environ.get("DCX_ALLOW_UNSAFE_CKPT", "0") not in ("", "0")
     try:
         blob = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:  # Lightning ckpts may pickle non-tensor hyper-parameters
+    except pickle.UnpicklingError as e:
+        if not allow_unsafe:
+            raise RuntimeError(
+                f"{path} needs a full (unsafe) unpickle: {str(e).splitlines()[0]}  -- if you trust the file pass "
+                "allow_unsafe=True or set DCX_ALLOW_UNSAFE_CKPT=1") from e
         blob = torch.load(path, map_location="cpu", weights_only=False)
     raw = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
     sd: StateDict = {}

@@ -169,6 +169,16 @@ int dcx_last_timings(float* h_ms4);
  * epi: 0 = BN+ReLU, 1 = raw (1x1 heads), 2 = RefineNet head; "" when no instantiation fits */
 const char* dcx_conv_pick_name(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi);
 
+/* ---- deterministic mode -------------------------------------------------------------------
+ * By default the launcher picks, per layer and launch size, between three kernel families (direct implicit GEMM, 1-D
+ * and 2-D Winograd): results are bit-reproducible for a given (shape, batch, device), but a frame's logits may differ
+ * in their last bits between batch sizes (the families round differently; arg-max outputs agree except on exact
+ * near-ties, see DESIGN.md "Numerics").  dcx_set_deterministic(1) (or DCX_DETERMINISTIC=1 in the environment) forces
+ * the direct kernels everywhere: one summation order per output element, independent of batch size, tile and CU
+ * count, at about 0.6x the default throughput.  Process-global; set it before launching work.                        */
+int dcx_set_deterministic(int enabled);
+int dcx_get_deterministic(void);
+
 /* ---- instrumentation: per-launch profile of the MFMA convolution kernel (roofline) ---------
  * While enabled, every launch of the convolution kernel is bracketed by two hipEvents on its
  * stream and recorded.  dcx_profile_enable(1) clears the record list.  After the caller has

@@ -637,6 +637,32 @@ def test_hazard_soak_repeated_runs_are_bit_identical(dev):
     _report("hazard_soak", report)
 
 
+def test_deterministic_mode_is_batch_invariant(dev):
+    """by default the kernel family depends on the launch size, so a frame's logits may differ in the last bits
+    between B=1 and B=32.  set_deterministic(True) pins the direct kernels: logits bit-identical alone / inside a batch."""
+    from deepcharuco_amd import _lib
+    from deepcharuco_amd.inference import set_deterministic
+    from deepcharuco_amd.models.net import dcModel
+    frames = W.synthetic_frames("board", 4321, 32, 240, 320)
+    det = dcModel(16, W.synthetic_state_dict("detector", 1234), dev)
+    d = torch.from_numpy(frames).to(dev)
+    try:
+        set_deterministic(True)
+        assert _lib.lib().dcx_get_deterministic() == 1
+        assert b"wino" not in _lib.lib().dcx_conv_pick_name(32, 64, 240, 320, 64, 3, 1, 0)
+        full = det.forward_u8(d)
+        for b in (0, 9, 31):
+            one = det.forward_u8(d[b:b + 1])
+            assert torch.equal(one["loc"][0], full["loc"][b]) and torch.equal(one["ids"][0], full["ids"][b])
+    finally:
+        set_deterministic(False)
+    assert b"wino2" in _lib.lib().dcx_conv_pick_name(32, 64, 240, 320, 64, 3, 1, 0)
+    dflt = det.forward_u8(d)
+    one = det.forward_u8(d[:1])
+    _report("default_mode_b1_vs_b32_logit_diff", float((one["loc"][0] - dflt["loc"][0]).abs().max()))
+    assert (one["loc"][0] - dflt["loc"][0]).abs().max() <= LOGIT_ATOL
+
+
 def test_colour_bgr_input_through_the_gpu_path(dev, golden_tiny):
     """A real colour image (the fixtures replicate gray x3): infer_image converts with bgr2gray and must equal the oracle
     fed with the oracle's own bgr2gray; when OpenCV is importable the formula is also checked against cv2 itself."""

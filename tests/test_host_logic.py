@@ -107,6 +107,35 @@ def test_bgr2gray_host():
     assert np.array_equal(bgr2gray(d["bgr"]), d["gray"])
 
 
+def test_checkpoint_reader_never_unpickles_code_silently(tmp_path):
+    """weights_only=True is the default; a checkpoint that needs a full unpickle is refused unless the caller
+    opts in; a missing / truncated file raises its own error and is not retried unsafely."""
+    import pickle
+    import torch
+    sd = W.synthetic_state_dict("refinenet", 3)
+    good = str(tmp_path / "good.ckpt")
+    W.save_lightning_style_checkpoint(good, sd)
+    assert W.state_dict_sha256(W.state_dict_from_checkpoint(good, "refinenet"), "refinenet") == W.state_dict_sha256(sd, "refinenet")
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > " + str(tmp_path / "pwned"),))
+    bad = str(tmp_path / "bad.ckpt")
+    torch.save({"state_dict": {f"model.{k}": torch.from_numpy(v) for k, v in sd.items()}, "hyper_parameters": Evil()}, bad)
+    with pytest.raises(RuntimeError, match="unsafe"):
+        W.state_dict_from_checkpoint(bad, "refinenet")
+    assert not os.path.exists(tmp_path / "pwned")
+    with pytest.raises(FileNotFoundError):
+        W.state_dict_from_checkpoint(str(tmp_path / "missing.ckpt"), "refinenet")
+    trunc = str(tmp_path / "trunc.ckpt")
+    open(trunc, "wb").write(open(good, "rb").read()[:1000])
+    with pytest.raises(Exception) as ei:
+        W.state_dict_from_checkpoint(trunc, "refinenet")
+    assert not isinstance(ei.value, pickle.UnpicklingError) or "unsafe" not in str(ei.value)
+    out = W.state_dict_from_checkpoint(bad, "refinenet", allow_unsafe=True)      # explicit opt-in works (and runs the payload)
+    assert os.path.exists(tmp_path / "pwned") and "conv1a.weight" in out
+
+
 def test_solve_pnp_short_circuit():
     from deepcharuco_amd.inference import solve_pnp
     assert solve_pnp(np.zeros((3, 3)), 5, 5, 0.01, None, None) == (False, None, None)
