@@ -39,6 +39,7 @@
 #include "dcx_common.h"
 
 typedef float dcx_f32x16 __attribute__((ext_vector_type(16)));
+typedef float dcx_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int dcx_u32x4 __attribute__((ext_vector_type(4)));
 
 #define DCX_CCH 16  // input channels per LDS chunk ("unit" of the software pipeline)

@@ -9,8 +9,9 @@
 //     columns  v[xi][nu]:  v0 = t[xi][0]-t[xi][2] v1 = t[xi][1]+t[xi][2] v2 = t[xi][2]-t[xi][1] v3 = t[xi][1]-t[xi][3]
 //     weights  u = G g G^T, transformed on the host in fp32 (rows first, then columns; h1 = ((h0+h1)+h2)*0.5f ...)
 //     m[xi][nu] += u[xi][nu] * v[xi][nu]                                   (16 accumulators = 256 registers per lane)
-//     y[i][j] = sum over (xi, nu), xi-major ascending, of AT[i][xi]*AT[j][nu]*m[xi][nu],  AT = [[1,1,1,0],[0,1,-1,-1]]
-//               (sequential adds / subtracts; the first non-zero term initialises)
+//     y[i][j] = 0;  for p = xi*4 + nu ascending:  y[i][j] = fmaf(AT[i][xi]*AT[j][nu], m[xi][nu], y[i][j]),
+//               AT = [[1,1,1,0],[0,1,-1,-1]]  (a sequential fmaf chain over ALL 16 positions, zero coefficients included:
+//               it runs on the matrix cores, see "Output transform" below)
 //
 // GEMM view: 16 independent GEMMs, M = cout, N = tiles, K = cin.  A wave owns 32 couts x 32 tiles x 16 positions; its
 // 256 accumulator registers live in AGPRs (one workgroup of 4 waves per CU, the whole 512-register file per lane);
@@ -221,6 +222,14 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
         sP[cq_pad + i] = reinterpret_cast<const float4*>(a.beta)[i];
         if (C::EPI == DCX_EPI_HEAT) sP[2 * cq_pad + i] = reinterpret_cast<const float4*>(a.head_w)[i];
     }
+    // output-transform coefficients T[k = 2i + j][p = 4 xi + nu] = AT[i][xi] * AT[j][nu] as [k][p] floats (256 B)
+    float* sT = reinterpret_cast<float*>(sP + 3 * cq_pad);
+    if (tid < 64) {
+        const int k = tid >> 4, p = tid & 15, i = k >> 1, j = k & 1, xi = p >> 2, nu = p & 3;
+        const int ci = i == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : xi == 1 ? 1 : -1);
+        const int cj = j == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : nu == 1 ? 1 : -1);
+        sT[tid] = (float)(ci * cj);
+    }
     const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
 
     // Accumulators are only ever defined by inline asm with an AGPR constraint: a C++ "acc = 0" makes the loop-carried
@@ -357,11 +366,10 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[6 + 3 * u] = __builtin_amdgcn_s_memtime();
         if (!ZERO && c == nch - 1) {
             // ---- epilogue: 2-D output transform, BN, ReLU (, pool | head), store -----------------------
-            // (the MFMAs are inline asm, so the compiler does not know the MFMA -> v_accvgpr_read distance; the code between
-            //  the last MFMA and the first read is far longer than the 18 wait states required, the nops make it explicit)
+            // (the MFMAs are inline asm, so the compiler does not know the distance between the last 16-pass MFMA and the first
+            //  instruction that reads an accumulator as srcB: 18 wait states required, the nops make 20 explicit)
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-            // re-define the accumulators here (empty asm, AGPR class): the AGPR -> VGPR copies the transform below needs are
-            // then created inside this block instead of being hoisted into the k-loop (where hipcc otherwise puts them)
+            // re-define the accumulators here (empty asm, AGPR class): keeps every use of them inside this block
 #pragma unroll
             for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
             const int oy0 = cur.ty * C::TH + 2 * qty, ox0 = cur.tx * C::TW + 2 * qtx;
@@ -376,49 +384,67 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
                                                : ((unsigned)half * plane + (unsigned)(oy0 * ws + ox0)) * 16u)
                                     + (C::G > 1 ? (unsigned)q_img * (unsigned)a.out_cq_total * plane * 16u : 0u);
             float hsum[4] = {0.f, 0.f, 0.f, 0.f};
-            // Output transform, position-outer: y[k = 2i+j] = sum over positions p = xi*4 + nu (ascending) of
-            // AT[i][xi] * AT[j][nu] * m[p], AT = [[1,1,1,0],[0,1,-1,-1]] -- the first non-zero term initialises, the others
-            // are added or subtracted in order (this order is part of the kernel's numerical specification).  One
-            // accumulator (16 registers) is copied out of the AGPRs at a time; the separable form needs 24 instead of 32
-            // float4 operations per cout quad but all 256 accumulator registers at once, which spills.
+            // Output transform ON THE MATRIX CORES.  An fp32 MFMA occupies the vector ALU (tools/ubench/mfma_fill.hip,
+            // mfma_overlap.hip: no VALU instruction of any wave overlaps it), so the 256 v_accvgpr_read + ~260 packed adds of
+            // a VALU transform were pure serial time (~3,600 cycles per work item).  v_mfma_f32_4x4x1_16b_f32 (16 blocks of
+            // 4 lanes, K = 1, 8 cycles) computes D_k(lane) = A(lane 4*(lane/4) + k) * B(lane) + C_k(lane): with B = one
+            // accumulator register read STRAIGHT FROM ITS AGPR (srcB may be an AccVGPR) and A = the per-lane constant
+            // T[k = lane % 4][p], sixteen of them chained over p give the lane its four outputs y[k] = sum_p T[k][p] m[p]
+            // as an exact sequential fmaf chain (coefficients 0, +-1: every product is exact) -- no accumulator ever passes
+            // through the vector ALU.  256 such MFMAs = 2,048 cycles per work item (probe: tools/ubench/mfma4x4_probe.hip;
+            // dependent accumulations must be >= 4 instructions apart, hence the four interleaved chains of a cout quad).
+            float cf[16];
+            {
+                const float4* tp = reinterpret_cast<const float4*>(sT + (lane & 3) * 16);
 #pragma unroll
-            for (int gh = 0; gh < 2; ++gh) {     // two cout quads at a time (32 + 16 live registers)
-            if (gh == 1) {       // again: keeps hipcc from copying whole 16-register accumulators for the second half
-#pragma unroll
-                for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 t4 = tp[q4];
+                    cf[4 * q4] = t4.x; cf[4 * q4 + 1] = t4.y; cf[4 * q4 + 2] = t4.z; cf[4 * q4 + 3] = t4.w;
+                }
             }
-            float4 yq[4][2];     // [k][g - 2*gh]
+#pragma unroll
+            for (int gh = 0; gh < 2; ++gh) {     // two cout quads (8 accumulator registers, 8 chains) at a time
+            dcx_f32x4 e[2][4];                    // e[g2][cc][k]: output k of cout 4*(2*gh+g2) + cc
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                __builtin_amdgcn_sched_barrier(0);
-                const int xi = p >> 2, nu = p & 3;
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
-                    const int g = 2 * gh + g2;
-                    const float4 m = make_float4(acc[p][4 * g + 0], acc[p][4 * g + 1], acc[p][4 * g + 2], acc[p][4 * g + 3]);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int i = k >> 1, jj = k & 1;
-                        const int ci = i == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : xi == 1 ? 1 : -1);
-                        const int cj = jj == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : nu == 1 ? 1 : -1);
-                        const int cf = ci * cj;
-                        const int first = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 4 : 5;
-                        if (cf != 0) {
-                            if (p == first) yq[k][g2] = m;
-                            else yq[k][g2] = cf > 0 ? add4(yq[k][g2], m) : sub4(yq[k][g2], m);
-                        }
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int r = 4 * (2 * gh + g2) + cc;
+                        if (p == 0) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=v"(e[g2][cc]) : "v"(cf[0]), "a"(acc[0][r]));
+                        else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(e[g2][cc]) : "v"(cf[p]), "a"(acc[p][r]));
                     }
                 }
             }
+            // 2-pass MFMA result -> VALU read needs wait states hipcc does not know about (asm); this statement also
+            // (re)defines all eight results, so no read of them can be scheduled above it
+            asm volatile("s_nop 7" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]),
+                                     "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[1][2]), "+v"(e[1][3]));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
                 const int g = 2 * gh + g2;
                 const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 8 + 2 * g + half;
                 const float4 al = sP[cq], be = sP[cq_pad + cq];
-                float4 y[4];     // y[2*i + j]
+                // BN: an MFMA result holds the four outputs k of ONE cout, so y = fma(e, alpha[cout], beta2[cout]) is a
+                // v_pk_fma_f32 over the pair (k, k+1) with alpha / beta2 broadcast by op_sel; ReLU (or the pooling max) then
+                // writes the value where the float4 store over the quad's four couts wants it -- no register shuffling
+                const dcx_f32x2 al01 = {al.x, al.y}, al23 = {al.z, al.w}, be01 = {be.x, be.y}, be23 = {be.z, be.w};
+                dcx_f32x2 bn[4][2];     // [cc][k / 2]
 #pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = dcx_fma4(yq[k][g2], al, be);
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int kp = 0; kp < 2; ++kp) {
+                        const dcx_f32x2 x = {e[g2][cc][2 * kp], e[g2][cc][2 * kp + 1]};
+                        const dcx_f32x2 aa = cc < 2 ? al01 : al23, bb = cc < 2 ? be01 : be23;
+                        if ((cc & 1) == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(bn[cc][kp]) : "v"(x), "v"(aa), "v"(bb));
+                        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(bn[cc][kp]) : "v"(x), "v"(aa), "v"(bb));
+                    }
+                float4 y[4];     // y[2*i + j] over the quad's four couts (un-ReLU'd; consumers below apply their max)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    y[k] = make_float4(bn[0][k >> 1][k & 1], bn[1][k >> 1][k & 1], bn[2][k >> 1][k & 1], bn[3][k >> 1][k & 1]);
                 char* dst = obase + (size_t)((unsigned)(2 * g) * plane * 16u) + lane_off;
                 if (C::POOL) {
                     float4 v;
@@ -537,7 +563,7 @@ static int dcx_conv_wino2_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
     const long resident = (long)dcx_device_cu_count();      // one workgroup per CU
     const long blocks = items < resident ? items : resident;
-    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 12;
+    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 12 + 256;      // + alpha, beta2, head weights, output-transform table
     if (lds > 160 * 1024) return DCX_E_SHAPE;
     static bool attr_set[DCX_MAX_DEVICES] = {};      // the attribute is per device (multi-GPU processes)
     const int dev_i = dcx_current_device();

@@ -83,11 +83,14 @@ def select_fixed_k_frames(kind: str, seed: int, batch: int, height: int, width: 
     keep: List[np.ndarray] = [] if first is None else [f for f in first]
     kept_ids: List[int] = [-1] * len(keep)
     j = 0
+    seen: List[int] = []
     while len(keep) < batch:
         if j >= max_candidates:
-            raise RuntimeError(f"only {len(keep)} of {batch} frames with exactly {k} corners among {j} candidates")
+            raise RuntimeError(f"only {len(keep)} of {batch} frames with exactly {k} corners among {j} candidates "
+                               f"(corner counts seen: min {min(seen)}, median {int(np.median(seen))}, max {max(seen)})")
         cand = W.synthetic_frames(kind, seed + j, chunk, height, width)
         counts = frame_counts(torch.from_numpy(cand).to(dev), dc, dust_bin_ids)
+        seen += counts.tolist()
         for i in np.nonzero(counts == k)[0]:
             if len(keep) < batch:
                 keep.append(cand[i])

@@ -120,8 +120,8 @@ void dcx_oracle_conv_wino_exact(const float* x, int n, int cin, int h, int w, co
  *     columns  v[xi][0] = t[xi][0]-t[xi][2]  v1 = t1+t2  v2 = t2-t1  v3 = t1-t3
  *     weights  h[xi][kx] over ky: h0 = g0, h1 = ((g0+g1)+g2)*0.5f, h2 = ((g0-g1)+g2)*0.5f, h3 = g2; then the same over kx
  *   m[xi][nu] = 0;  for chunk c0 / s / j / k:  m = fmaf(u[ci], v[ci], m),  ci = c0 + 8s + 4k + j
- *   y[i][j] = sum over (xi, nu), xi-major ascending, of AT[i][xi]*AT[j][nu]*m[xi][nu], AT = [[1,1,1,0],[0,1,-1,-1]]
- *             (sequential adds / subtracts, the first non-zero term initialises)
+ *   y[i][j] = 0; for p = 4 xi + nu ascending: y[i][j] = fmaf(AT[i][xi]*AT[j][nu], m[xi][nu], y[i][j]), AT = [[1,1,1,0],[0,1,-1,-1]]
+ *             (the kernel runs this chain on the matrix cores, v_mfma_f32_4x4x1: all 16 terms, zero coefficients included)
  *   out = max(fmaf(y, alpha, fmaf(bias, alpha, beta)), 0) */
 void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
                                  const float* alpha, const float* beta, int cout, int pad, float* y) {
@@ -166,21 +166,16 @@ void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, c
                                     for (int xi = 0; xi < 4; ++xi)
                                         for (int nu = 0; nu < 4; ++nu) m[xi][nu] = fmaf(u[xi][nu], v[xi][nu], m[xi][nu]);
                                 }
-                    /* output transform, position-outer: o[i][j] = sum over xi, nu (xi-major, ascending) of
-                     * AT[i][xi]*AT[j][nu]*m[xi][nu], AT = [[1,1,1,0],[0,1,-1,-1]]; the first non-zero term initialises */
+                    /* output transform: a sequential fmaf chain over all 16 positions (xi-major, ascending) with the coefficient
+                     * AT[i][xi]*AT[j][nu] in {0, +1, -1}, AT = [[1,1,1,0],[0,1,-1,-1]], starting from +0 */
                     static const int AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
                     float o[2][2];
                     for (int i = 0; i < 2; ++i)
                         for (int jj = 0; jj < 2; ++jj) {
-                            int started = 0;
                             float acc2 = 0.0f;
                             for (int xi = 0; xi < 4; ++xi)
-                                for (int nu = 0; nu < 4; ++nu) {
-                                    const int cf = AT[i][xi] * AT[jj][nu];
-                                    if (cf == 0) continue;
-                                    if (!started) { acc2 = m[xi][nu]; started = 1; }   /* the first coefficient is always +1 */
-                                    else acc2 = cf > 0 ? acc2 + m[xi][nu] : acc2 - m[xi][nu];
-                                }
+                                for (int nu = 0; nu < 4; ++nu)
+                                    acc2 = fmaf((float)(AT[i][xi] * AT[jj][nu]), m[xi][nu], acc2);
                             o[i][jj] = acc2;
                         }
                     const float b2 = fmaf(bias[co], alpha[co], beta[co]);

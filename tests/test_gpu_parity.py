@@ -512,9 +512,9 @@ def test_config5_bs32_1280x960_fixed_k16(dev):
     from deepcharuco_amd.models.net import dcModel, lModel
     from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
     calib = torch.from_numpy(W.synthetic_frames("board4", 20000, 32, 960, 1280)).to(dev)
-    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 91), calib, dev, per_frame=16)
+    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), calib, dev, per_frame=16)
     del calib
-    sd_rn = W.synthetic_state_dict("refinenet", 92)
+    sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
     frames, kept = WL.select_fixed_k_frames("board4", 20000, 32, 960, 1280, 16, dc, dev)
     assert frames.shape == (32, 960, 1280) and len(set(kept)) == 32

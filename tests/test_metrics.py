@@ -130,16 +130,24 @@ def test_accuracy_harness_over_infer_batch_outputs():
     t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
     exp_ref = [O.infer_image(None, 16, t_dc, t_rn, gray=f) for f in frames]
     exp_raw = [O.infer_image(None, 16, t_dc, None, gray=f) for f in frames]
-    uniq = [b for b in range(8) if exp_ref[b].ndim == 2 and len(set(exp_ref[b][:, 2])) == exp_ref[b].shape[0]]
-    assert len(uniq) >= 2
+    def dedup(a):      # the reference's metric assumes an id occurs once per TARGET frame: keep each id's first corner
+        _, first = np.unique(a[:, 2], return_index=True)
+        return a[np.sort(first)]
+    have = [b for b in range(8) if exp_ref[b].ndim == 2]
+    assert len(have) >= 5
+    targets = [dedup(exp_ref[b]) for b in have]
+    vals = {}
+    for name, res in (("hip_ref", got_ref), ("oracle_ref", exp_ref), ("hip_raw", got_raw), ("oracle_raw", exp_raw)):
+        m = PM.DC_Metrics(16)
+        m.update_keypoints([res[b] for b in have], targets)
+        vals[name] = (float(m.distance), float(m.ratio))
+    assert vals["hip_ref"] == vals["oracle_ref"] and vals["hip_raw"] == vals["oracle_raw"]
+    assert vals["hip_raw"][0] > 0.0 and 0.0 < vals["hip_ref"][1] <= 1.0
+    one = [b for b in have if len(set(exp_ref[b][:, 2])) == exp_ref[b].shape[0]]      # frames whose ids are unique
     m = PM.DC_Metrics(16)
-    m.update_keypoints([got_ref[b] for b in uniq], [exp_ref[b] for b in uniq])
-    assert float(m.distance) == 0.0 and float(m.ratio) == 1.0
-    m_raw, o_raw = PM.DC_Metrics(16), PM.DC_Metrics(16)
-    m_raw.update_keypoints([got_raw[b] for b in uniq], [exp_ref[b] for b in uniq])
-    o_raw.update_keypoints([exp_raw[b] for b in uniq], [exp_ref[b] for b in uniq])
-    assert float(m_raw.distance) == float(o_raw.distance) > 0.0
-    b = uniq[0]
+    m.update_keypoints([got_ref[b] for b in one], [exp_ref[b] for b in one])
+    assert len(one) >= 1 and float(m.distance) == 0.0 and float(m.ratio) == 1.0
+    b = one[0]
     with contextlib.redirect_stdout(io.StringIO()):
         a = PM.pixel_error(got_raw[b].astype(np.float64), got_ref[b], exp_ref[b])
         e = PM.pixel_error(exp_raw[b].astype(np.float64), exp_ref[b], exp_ref[b])

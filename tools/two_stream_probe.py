@@ -8,11 +8,11 @@ from deepcharuco_amd.inference import infer_batch_device
 from deepcharuco_amd.models.net import dcModel, lModel
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
 dev = torch.device("cuda", 0)
-frames = torch.from_numpy(W.synthetic_frames("board", 1000, 64, 240, 320)).to(dev)
+frames = torch.from_numpy(W.synthetic_frames("board", 1000, 128, 240, 320)).to(dev)
 sd = W.synthetic_state_dict("detector", 1234); sd["convDb.bias"][16] += np.float32(3.75)
 sd_rn = W.synthetic_state_dict("refinenet", 1235)
 # one model pair per stream (the pipeline workspace is owned by the detector object and keyed by the current stream)
-pairs = [(lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(sd_rn, dev))) for _ in range(2)]
+pairs = [(lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(sd_rn, dev))) for _ in range(4)]
 
 def run(nstreams, B, steps=20):
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
@@ -30,4 +30,4 @@ def run(nstreams, B, steps=20):
     k = float(np.mean([int(x) for o in outs for x in o[:B].cpu().numpy()]))
     print(f"{nstreams} stream(s) x B={B}: {nstreams * B * steps / dt:8.1f} fps   ({1e3 * dt / steps:.3f} ms per round, {k:.1f} corners/frame)")
 
-run(1, 32); run(2, 16); run(2, 32); run(1, 64); run(1, 32)
+run(1, 32); run(2, 16); run(4, 8); run(1, 32); run(2, 16); run(3, 11); run(2, 32); run(4, 16); run(1, 64)
