@@ -308,9 +308,25 @@ extern "C" size_t dcx_detector_workspace_bytes(const dcx_detector* det, int batc
     return det_layout(det->n_ids, batch, height, width).total;
 }
 
+namespace {
+// conv1a .. convPa|convDa; with_heads: also the two raw 1x1 heads into the workspace's C4 logit buffers (dcModel.forward).
+// Without them the 512-channel activation is left in buf0 for the fused tail kernel (dcx_tail.hip).
+int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch,
+                 const float* d_images_f32, int batch, int height, int width, void* d_ws, size_t ws_bytes,
+                 bool with_heads, float* d_loc_nchw, float* d_ids_nchw, void* stream);
+}  // namespace
+
 extern "C" int dcx_detector_forward(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch,
                                     const float* d_images_f32, int batch, int height, int width, void* d_ws,
                                     size_t ws_bytes, float* d_loc_nchw, float* d_ids_nchw, void* stream) {
+    return detector_run(det, d_frames_u8, frame_stride, pitch, d_images_f32, batch, height, width, d_ws, ws_bytes, true,
+                        d_loc_nchw, d_ids_nchw, stream);
+}
+
+namespace {
+int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch,
+                 const float* d_images_f32, int batch, int height, int width, void* d_ws, size_t ws_bytes,
+                 bool with_heads, float* d_loc_nchw, float* d_ids_nchw, void* stream) {
     if (!det || !d_ws) return DCX_E_ARG;
     if ((d_frames_u8 == nullptr) == (d_images_f32 == nullptr)) return DCX_E_ARG;
     if (batch <= 0 || height < 8 || width < 8 || (height & 7) || (width & 7)) return DCX_E_SHAPE;
@@ -351,6 +367,7 @@ extern "C" int dcx_detector_forward(const dcx_detector* det, const uint8_t* d_fr
         rc = dcx_launch_conv_mfma(a, 3, 0, DCX_EPI_BNRELU, s);
         if (rc) return rc;
     }
+    if (!with_heads) return 0;
     {   // convPb 1x1 (net.py:74): channels 0..255 -> 65 logits; image flattened to 1 x cells
         DcxConvArgs a = conv_args(det->head_loc, dst, batch, 128, 0, 1, hc * wc, 0, 0, loc, 17, nullptr);
         rc = dcx_launch_conv_mfma(a, 1, 0, DCX_EPI_RAW, s);
@@ -365,6 +382,7 @@ extern "C" int dcx_detector_forward(const dcx_detector* det, const uint8_t* d_fr
     if (d_ids_nchw) { rc = dcx_c4_to_nchw(ids, batch, det->n_ids + 1, hc, wc, d_ids_nchw, stream); if (rc) return rc; }
     return 0;
 }
+}  // namespace
 
 extern "C" int dcx_detector_decode(const dcx_detector* det, int batch, int height, int width, void* d_ws,
                                    int dust_bin, int kmax, int32_t* d_counts, int32_t* d_rows, int32_t* d_loc_argmax,
@@ -512,13 +530,24 @@ extern "C" int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf, c
     char* ws = (char*)d_ws;
     int rc = timing_mark(0, s);
     if (rc) return rc;
-    rc = dcx_detector_forward(det, d_frames_u8, frame_stride, pitch, nullptr, batch, height, width, ws + L.det,
-                              L.table - L.det, nullptr, nullptr, stream);
+    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
+    // detector up to convPa|convDa, then ONE kernel for the 1x1 heads + per-cell arg-max + dust-bin rule (the logits never
+    // reach HBM; dcModel.forward keeps the separate heads because it has to return them), then the ordered compaction
+    rc = detector_run(det, d_frames_u8, frame_stride, pitch, nullptr, batch, height, width, ws + L.det, L.table - L.det,
+                      false, nullptr, nullptr, stream);
     if (rc) return rc;
     if ((rc = timing_mark(1, s))) return rc;
-    rc = dcx_detector_decode(det, batch, height, width, ws + L.det, dust_bin, kmax, d_counts, d_rows, nullptr, nullptr,
-                             stream);
-    if (rc) return rc;
+    {
+        const DetWs D = det_layout(det->n_ids, batch, height, width);
+        const int hc = height / 8, wc = width / 8;
+        const float* act = (const float*)(ws + L.det + D.buf0);
+        int32_t* codes = (int32_t*)(ws + L.det + D.codes);
+        rc = dcx_launch_tail(act, batch, hc * wc, det->head_loc.w, det->head_loc.bias, det->head_ids.w, det->head_ids.bias,
+                             det->head_ids.cout_pad, det->n_ids + 1, dust_bin, codes, nullptr, nullptr, s);
+        if (rc) return rc;
+        rc = dcx_launch_compact(codes, batch, hc, wc, dust_bin, kmax, d_counts, d_rows, s);
+        if (rc) return rc;
+    }
     if (rf == nullptr) {
         if ((rc = timing_mark(2, s))) return rc;
         if ((rc = timing_mark(3, s))) return rc;

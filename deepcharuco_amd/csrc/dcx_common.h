@@ -79,6 +79,13 @@ struct DcxLogitView {
 int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, int n_ids1, int hc, int wc,
                       int dust_bin, int kmax, int32_t* counts, int32_t* rows,
                       int32_t* loc_argmax, int32_t* ids_argmax, int32_t* codes_scratch, hipStream_t s);
+// fused detector tail (dcx_tail.hip): 1x1 heads + per-cell arg-max + dust-bin rule -> packed codes (loc | id << 8)
+int dcx_launch_tail(const float* act_c4_512, int batch, int cells, const float* w_loc, const float* b_loc,
+                    const float* w_ids, const float* b_ids, int ids_cout_pad, int n_ids1, int dust_bin,
+                    int32_t* codes, int32_t* loc_argmax, int32_t* ids_argmax, hipStream_t s);
+// ordered compaction of packed codes into per-frame rows (dcx_misc.hip)
+int dcx_launch_compact(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
+                       int32_t* rows, hipStream_t s);
 int dcx_launch_refine_finalize(const float* part_val, const int* part_idx, int tiles, int wo,
                                int max_patches, const int* total, const int32_t* table,
                                int32_t* corners, float* xy, hipStream_t s);

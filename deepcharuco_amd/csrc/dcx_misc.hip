@@ -281,6 +281,15 @@ int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, 
     return (int)hipGetLastError();
 }
 
+int dcx_launch_compact(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
+                       int32_t* rows, hipStream_t s) {
+    if (!codes || !counts || !rows) return DCX_E_ARG;
+    if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0) return DCX_E_SHAPE;
+    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
+    hipLaunchKernelGGL(dcx_compact_kernel, dim3((unsigned)batch), dim3(256), 0, s, codes, hc, wc, dust_bin, kmax, counts, rows);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dcx_pred_to_keypoints(const float* d_loc, const float* d_ids, int batch, int n_loc, int n_ids1,
                                      int hc, int wc, int dust_bin, int kmax, int32_t* d_counts, int32_t* d_rows,
                                      int32_t* d_loc_argmax, int32_t* d_ids_argmax, void* stream) {
@@ -470,6 +479,37 @@ extern "C" int dcx_pre_image(const uint8_t* d_gray, float* d_out, size_t n, void
     if (n == 0) return 0;
     const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(dcx_pre_image_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_gray, d_out, n);
+    return (int)hipGetLastError();
+}
+
+// cv2.cvtColor(img, COLOR_BGR2GRAY) on 8-bit images (call site /root/reference/src/inference.py:40): OpenCV's fixed-point
+// formula with 14 fractional bits, gray = (1868 B + 9617 G + 4899 R + 8192) >> 14 -- integer arithmetic, so the device
+// result equals the host restatement (deepcharuco_amd/imgproc.py, oracle bgr2gray) bit for bit.  One thread = 4 pixels
+// (12 B in, 4 B out); the numpy version of this costs the host 150-300 us per 320x240 frame, more than half of a bs=1 call.
+__global__ __launch_bounds__(256) void dcx_bgr2gray_kernel(const uint8_t* __restrict__ bgr, long frame_stride, int pitch,
+                                                             int h, int w, uint8_t* __restrict__ gray) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= w) return;
+    const uint8_t* src = bgr + (size_t)b * frame_stride + (size_t)y * pitch + (size_t)x0 * 3;
+    uint8_t* dst = gray + ((size_t)b * h + y) * w + x0;
+    const int n = min(4, w - x0);
+    uint8_t g[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        const unsigned bb = src[3 * i], gg = src[3 * i + 1], rr = src[3 * i + 2];
+        g[i] = (uint8_t)((bb * 1868u + gg * 9617u + rr * 4899u + 8192u) >> 14);
+    }
+    if (n == 4 && ((w & 3) == 0)) *reinterpret_cast<uchar4*>(dst) = make_uchar4(g[0], g[1], g[2], g[3]);
+    else for (int i = 0; i < n; ++i) dst[i] = g[i];
+}
+
+extern "C" int dcx_bgr2gray(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
+                            uint8_t* d_gray, void* stream) {
+    if (!d_bgr || !d_gray) return DCX_E_ARG;
+    if (batch <= 0 || height <= 0 || width <= 0 || batch > 65535 || height > 65535 || pitch < 3 * width) return DCX_E_SHAPE;
+    const dim3 grid((unsigned)((width + 1023) / 1024), (unsigned)height, (unsigned)batch);
+    hipLaunchKernelGGL(dcx_bgr2gray_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_bgr, frame_stride, pitch, height, width,
+                       d_gray);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,96 @@
+"""hipGraph replay of one fixed-shape detect+refine call.
+
+The reference's own protocol is one frame per ``infer_image`` call (/root/reference/src/benchmark.py:37-53,
+pose_estimation.py:58-59): ~28 small kernel launches whose host-side enqueue cost, plus the host BGR->gray conversion,
+is a large part of a 0.5-0.7 ms call on MI355X.  ``GraphedPipeline`` captures the whole call once per shape --
+H2D of the frame from pinned memory, BGR->gray on the device (``dcx_bgr2gray``), the sync-free pipeline
+(``dcx_infer_batch``), D2H of the packed corner list -- into ONE hipGraph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm)
+and replays it per call: one launch from the host instead of ~30.  Results are those of ``infer_batch`` (same kernels,
+same order); a frame that fires more than ``kmax`` cells falls back to the eager path, which re-runs with a larger
+capacity.  Not thread-safe (one instance per thread / stream, like the C handles).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, unpack_results
+from .sharding import packed_len
+
+
+class GraphedPipeline:
+    def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 1, height: int = 240, width: int = 320,
+                 kmax: int = DEFAULT_KMAX, bgr: bool = True):
+        det = deepc.model if hasattr(deepc, "model") else deepc
+        ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
+        self.dev = det.device
+        self.dust_bin_ids, self.deepc, self.refinenet = dust_bin_ids, deepc, refinenet
+        self.batch, self.h, self.w, self.kmax, self.bgr = batch, height, width, kmax, bgr
+        L = _lib.lib()
+        shape = (batch, height, width, 3) if bgr else (batch, height, width)
+        n_out = packed_len(batch, kmax)
+        with torch.cuda.device(self.dev):
+            self.pin_in = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            self.dev_in = torch.empty(shape, dtype=torch.uint8, device=self.dev)
+            self.gray = torch.empty((batch, height, width), dtype=torch.uint8, device=self.dev) if bgr else self.dev_in
+            self.out_dev = torch.empty((n_out,), dtype=torch.int32, device=self.dev)
+            self.pin_out = torch.empty((n_out,), dtype=torch.int32).pin_memory()
+            nbytes = L.dcx_pipeline_workspace_bytes(det.handle, ref.handle if ref else None, batch, height, width, kmax)
+            if nbytes == 0:
+                raise ValueError("bad batch/shape for dcx_pipeline_workspace_bytes")
+            self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+            self.stream = torch.cuda.Stream()
+            self.pin_in.zero_()
+            with torch.cuda.stream(self.stream):          # eager warm-up: per-kernel attributes, lazy module loading
+                for _ in range(2):
+                    self._enqueue()
+            self.stream.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self._enqueue()
+        self._in_np = self.pin_in.numpy()
+        self._out_np = self.pin_out.numpy()
+
+    def _enqueue(self) -> None:
+        self.dev_in.copy_(self.pin_in, non_blocking=True)
+        if self.bgr:
+            _lib.check(_lib.lib().dcx_bgr2gray(self.dev_in.data_ptr(), self.h * self.w * 3, self.w * 3, self.batch, self.h,
+                                               self.w, self.gray.data_ptr(), _lib.current_stream()), "dcx_bgr2gray")
+        infer_batch_device(self.gray, self.dust_bin_ids, self.deepc, self.refinenet, self.kmax, out=self.out_dev, ws=self.ws)
+        self.pin_out.copy_(self.out_dev, non_blocking=True)
+
+    def run(self, frames: np.ndarray) -> List[np.ndarray]:
+        """frames: (B,H,W,3) BGR or (B,H,W) gray uint8 host array (as configured) -> list of B keypoint arrays."""
+        if frames.shape != self._in_np.shape or frames.dtype != np.uint8:
+            raise ValueError(f"expected uint8 frames of shape {self._in_np.shape}, got {frames.dtype} {frames.shape}")
+        np.copyto(self._in_np, frames)
+        with torch.cuda.device(self.dev):
+            self.graph.replay()
+            torch.cuda.current_stream().synchronize()
+        res, counts = unpack_results(self._out_np, self.batch, self.kmax, self.refinenet is not None)
+        if int(counts.max()) > self.kmax:                 # rare: capacity exceeded -> exact eager re-run
+            gray = frames if not self.bgr else self.gray.cpu().numpy()
+            res = infer_batch(gray, self.dust_bin_ids, self.deepc, self.refinenet, kmax=self.kmax)
+        return res
+
+
+_cache: dict = {}
+_CACHE_MAX = 8
+
+
+def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int, bgr: bool,
+                    kmax: int = DEFAULT_KMAX) -> Optional[GraphedPipeline]:
+    """One graph per (model pair, shape) for ``infer_image``; a small LRU (graphs pin ~25 MB of workspace per 320x240 shape)."""
+    det = deepc.model if hasattr(deepc, "model") else deepc
+    ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
+    key = (id(det), det.handle.value, id(ref), None if ref is None else ref.handle.value, dust_bin_ids, height, width, bgr, kmax)
+    p = _cache.pop(key, None)
+    if p is None:
+        p = GraphedPipeline(dust_bin_ids, deepc, refinenet, 1, height, width, kmax, bgr)
+        while len(_cache) >= _CACHE_MAX:
+            _cache.pop(next(iter(_cache)))
+    _cache[key] = p
+    return p

@@ -57,6 +57,13 @@ int dcx_refiner_destroy(dcx_refiner* rf);
 size_t dcx_detector_workspace_bytes(const dcx_detector* det, int batch, int height, int width);
 size_t dcx_refiner_workspace_bytes(const dcx_refiner* rf, int max_patches);
 
+/* ---- colour conversion: cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) call at inference.py:40 ---------
+ * 8-bit BGR frames (interleaved, row pitch / frame stride in BYTES) -> dense gray u8 [B][H][W] with OpenCV's 8-bit
+ * fixed-point formula gray = (1868 B + 9617 G + 4899 R + 8192) >> 14 (third-party arithmetic, not vendored in the
+ * reference: "parity unpinned" for this one step).                                                */
+int dcx_bgr2gray(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
+                 uint8_t* d_gray, void* stream);
+
 /* ---- pre-processing ------------------------------------------------------------------
  * pre_bgr_image models/model_utils.py:46-50:  out = (float(g) - 128) / 255 (IEEE division).
  * d_gray [n] u8 -> d_out [n] f32.                                                        */

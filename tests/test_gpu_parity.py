@@ -637,6 +637,60 @@ def test_hazard_soak_repeated_runs_are_bit_identical(dev):
     _report("hazard_soak", report)
 
 
+def test_bgr2gray_device_kernel_equals_the_fixed_point_formula(dev):
+    from deepcharuco_amd.imgproc import bgr2gray_device
+    rng = np.random.default_rng(3)
+    for shape in ((2, 37, 53, 3), (1, 240, 320, 3), (8, 10, 3)):
+        bgr = rng.integers(0, 256, shape, dtype=np.uint8)
+        got = bgr2gray_device(torch.from_numpy(bgr).to(dev)).cpu().numpy()
+        assert got.shape == shape[:-1] and np.array_equal(got, O.bgr2gray(bgr))
+    edge = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
+    assert np.array_equal(bgr2gray_device(torch.from_numpy(edge).to(dev)).cpu().numpy(), O.bgr2gray(edge))
+
+
+def test_hipgraph_replay_equals_eager_launches(dev, golden_tiny):
+    """infer_image replays ONE hipGraph per shape (upload, BGR->gray, ~28 kernels, download): results must equal the
+    eager path's and the oracle's, across shapes, with / without RefineNet, for a frame without corners, and a frame
+    over the capacity must fall back to the exact eager re-run."""
+    import deepcharuco_amd.inference as I
+    from deepcharuco_amd.graph import GraphedPipeline
+    from deepcharuco_amd.models.net import dcModel, lModel
+    dc, rn = _models(golden_tiny, dev)
+    t_dc, t_rn = O.to_torch_state_dict(golden_tiny.sd_dc), O.to_torch_state_dict(golden_tiny.sd_rn)
+    rng = np.random.default_rng(11)
+    imgs = []
+    for (h, w), seed in (((64, 96), 5), ((64, 96), 6), ((120, 160), 7), ((64, 96), 5)):
+        g = W.synthetic_frames("noise", seed, 1, h, w)[0].astype(np.int16)
+        imgs.append(np.clip(np.stack([g + rng.integers(-20, 21, g.shape), g, g + rng.integers(-20, 21, g.shape)], 2), 0, 255).astype(np.uint8))
+    assert I._graphs_enabled()
+    graphed = [I.infer_image(im, 16, dc, rn, device="cuda")[0] for im in imgs]
+    graphed_norn = [I.infer_image(im, 16, dc, None, device="cuda")[0] for im in imgs]
+    I._graph_state["enabled"] = False
+    try:
+        eager = [I.infer_image(im, 16, dc, rn, device="cuda")[0] for im in imgs]
+    finally:
+        I._graph_state["enabled"] = True
+    for im, a, b, c in zip(imgs, graphed, eager, graphed_norn):
+        exp = O.infer_image(im, 16, t_dc, t_rn)
+        assert a.shape == exp.shape and a.dtype == exp.dtype and np.array_equal(a, exp)
+        assert np.array_equal(a, b)
+        exp2 = O.infer_image(im, 16, t_dc, None)
+        assert c.dtype == exp2.dtype and np.array_equal(c, exp2)
+    assert sum(e.shape[0] for e in graphed if e.ndim == 2) > 5
+    # no corner at all -> np.array([]) through the graph as well
+    sd0 = {k: v.copy() for k, v in golden_tiny.sd_dc.items()}
+    sd0["convDb.bias"][16] = np.float32(1e4)
+    kp, _ = I.infer_image(imgs[0], 16, lModel(dcModel(16, sd0, dev)), rn, device="cuda")
+    assert kp.shape == (0,) and kp.dtype == np.float64
+    # capacity overflow inside a graphed call: exact eager re-run
+    gp = GraphedPipeline(16, dc, rn, batch=2, height=64, width=96, kmax=2, bgr=True)
+    with pytest.warns(UserWarning):
+        res = gp.run(np.stack([imgs[0], imgs[1]]))
+    assert all(np.array_equal(r, O.infer_image(im, 16, t_dc, t_rn)) for r, im in zip(res, imgs[:2]))
+    with pytest.raises(ValueError):
+        gp.run(imgs[2][None])
+
+
 def test_deterministic_mode_is_batch_invariant(dev):
     """by default the kernel family depends on the launch size, so a frame's logits may differ in the last bits
     between B=1 and B=32.  set_deterministic(True) pins the direct kernels: logits bit-identical alone / inside a batch."""
@@ -680,7 +734,7 @@ def test_colour_bgr_input_through_the_gpu_path(dev, golden_tiny):
     assert exp.ndim == 2 and exp.shape[0] > 0
 
 
-@pytest.mark.parametrize("n_ids", [8, 24])
+@pytest.mark.parametrize("n_ids", [8, 24, 40])
 def test_other_board_sizes_n_ids(dev, n_ids):
     """n_ids = (rows-1)*(cols-1) is a model parameter (configs.py:34-35): 3x5 and 5x7 boards, not only 16."""
     from deepcharuco_amd.inference import infer_batch
