@@ -51,6 +51,7 @@ struct DcxConvArgs {
     int cout_quads;        // valid output channel quads = ceil(cout / 4)
     int cout_real;         // un-padded output channels (profiling only)
     int tiles_x, tiles_y;
+    int xcd_walk;          // set by the launcher: XCD-aware item walk (dcx_conv_wino2.h)
 };
 
 // Picks a tile configuration for (ho, wo, cout_pad, pool, epi, ks) and launches.

@@ -553,6 +553,7 @@ int dcx_device_cu_count();   // dcx_conv_mfma.hip: CUs of the CURRENT device (ca
 constexpr int DCX_MAX_DEVICES = 64;
 int dcx_current_device();    // hipGetDevice() clamped to [0, DCX_MAX_DEVICES)
 int dcx_occupancy_override();
+int dcx_xcd_walk_enabled();   // DCX_XCD_WALK=0 keeps the flat item walk (A/B runs)
 
 template <class C>
 static int dcx_conv_launch_cfg(DcxConvArgs a, hipStream_t stream) {

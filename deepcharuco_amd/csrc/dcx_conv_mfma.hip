@@ -276,6 +276,12 @@ int dcx_device_cu_count() {
     return cus[dev];
 }
 
+int dcx_xcd_walk_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_XCD_WALK"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v;
+}
+
 int dcx_occupancy_override() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("DCX_OCC"); v = e ? atoi(e) : 0; }

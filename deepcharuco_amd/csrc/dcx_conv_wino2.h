@@ -81,13 +81,24 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
     int n_eff = a.n;
     if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
     const int total = ((n_eff + C::G - 1) / C::G) * n_ct * tiles;      // G > 1: one work item covers G images (tiles == 1)
-    int w = blockIdx.x;
-    if (w >= total) return;
+    // Work walk.  Flat: block b takes items b, b + grid, ...  XCD-aware (a.xcd_walk, grid a multiple of 8): block b runs on
+    // XCD b % 8 (observed dispatch order, used for speed only -- any placement is correct), so XCD x's blocks walk the x-th
+    // CONTIGUOUS eighth of the item list, slot b / 8 first, stride grid / 8: the 32 workgroups that share an L2 work on
+    // neighbouring tiles of the same images (and on both cout tiles of a 128-cout layer) at the same time, so the 2-pixel
+    // halos and the second read of the input are L2 hits instead of HBM / Infinity-Cache fetches (FETCH_SIZE A/B: profiles/).
+    int w = blockIdx.x, w_end = total, gstride = gridDim.x;
+    if (a.xcd_walk && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7;
+        const int lo = (int)(((long)total * x) >> 3);
+        w_end = (int)(((long)total * (x + 1)) >> 3);
+        gstride = gridDim.x >> 3;
+        w = lo + (blockIdx.x >> 3);
+    }
+    if (w >= w_end) return;
     if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
         a.clk_probe[0] = __builtin_amdgcn_s_memtime();
         a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
     }
-    const int gstride = gridDim.x;
     const int nch = a.cin / DCX_CCH;
     auto decode = [&](int wi) {
         DcxItem it;
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void dcx_conv_wino2_kernel(const DcxConvArg
         int cn = c + 1;
         bool has_next = true;
         if (cn == nch) {
-            if (w + gstride < total) { nxt = decode(w + gstride); cn = 0; }
+            if (w + gstride < w_end) { nxt = decode(w + gstride); cn = 0; }
             else { has_next = false; cn = c; }
         }
         const int buf = u & 1;
@@ -563,6 +574,7 @@ static int dcx_conv_wino2_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
     const long resident = (long)dcx_device_cu_count();      // one workgroup per CU
     const long blocks = items < resident ? items : resident;
+    a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
     const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 12 + 256;      // + alpha, beta2, head weights, output-transform table
     if (lds > 160 * 1024) return DCX_E_SHAPE;
     static bool attr_set[DCX_MAX_DEVICES] = {};      // the attribute is per device (multi-GPU processes)

@@ -802,6 +802,10 @@ def test_frame_stream_matches_oracle(dev):
     fs = FrameStream(16, dc, rn, batch=4, height=120, width=160, kmax=64, depth=2)
     chunks = [frames[i:i + 4] for i in range(0, 22, 4)]       # 5 full batches + one of 2 frames
     out = list(fs.run(chunks))
+    fs2 = FrameStream(16, dc, rn, batch=4, height=120, width=160, kmax=64, depth=3, compute_streams=2)   # batches on alternating streams
+    out2 = list(fs2.run(chunks))
+    assert [t for t, _ in out2] == list(range(6))
+    assert all(np.array_equal(a, b) for (_, ra), (_, rb) in zip(out, out2) for a, b in zip(ra, rb))
     assert [t for t, _ in out] == list(range(6))
     flat = [a for _, res in out for a in res]
     t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(W.synthetic_state_dict("refinenet", 56))
