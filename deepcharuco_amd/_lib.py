@@ -71,6 +71,7 @@ SIGNATURES = {
     "dcx_set_timing": (_i, [_i]),
     "dcx_last_timings": (_i, [C.POINTER(C.c_float)]),
     "dcx_conv_pick_name": (C.c_char_p, [_i] * 8),
+    "dcx_conv_pick_name_ups": (C.c_char_p, [_i] * 9),
     "dcx_set_deterministic": (_i, [_i]),
     "dcx_get_deterministic": (_i, []),
     "dcx_profile_enable": (_i, [_i]),

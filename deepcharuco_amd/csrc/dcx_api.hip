@@ -66,6 +66,33 @@ std::vector<float> pack_conv_wino2(const float* w, int cout, int cin, int cout_p
     return out;
 }
 
+// 3x3 OIHW -> the four phase kernels of a 3x3 convolution over a nearest-x2 up-sampled input (dcx_conv_mfma.h, PH variant):
+// [phase = 2a + b][tap = 2 dy + dx][cin/4][cout_pad][4].  Row sets: a = 0: dy 0 <- {ky 0}, dy 1 <- {ky 1, 2}; a = 1: dy 0 <-
+// {ky 0, 1}, dy 1 <- {ky 2}; columns alike with b.  fp32, rows first then columns, left to right (restated by
+// oracle/conv_exact.c: dcx_oracle_conv_ups2_exact).
+std::vector<float> pack_conv_ups2(const float* w, int cout, int cin, int cout_pad) {
+    const int cq = cin / 4;
+    std::vector<float> out((size_t)16 * cq * cout_pad * 4, 0.0f);
+    static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};   // [a or b][dy or dx]: inclusive range of ky / kx
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i) {
+            const float* g = w + ((size_t)o * cin + i) * 9;
+            for (int ph = 0; ph < 4; ++ph)
+                for (int tap = 0; tap < 4; ++tap) {
+                    const int a = ph >> 1, b = ph & 1, dy = tap >> 1, dx = tap & 1;
+                    float r[3];
+                    for (int kx = 0; kx < 3; ++kx) {
+                        r[kx] = g[lo[a][dy] * 3 + kx];
+                        for (int ky = lo[a][dy] + 1; ky <= hi[a][dy]; ++ky) r[kx] = r[kx] + g[ky * 3 + kx];
+                    }
+                    float v = r[lo[b][dx]];
+                    for (int kx = lo[b][dx] + 1; kx <= hi[b][dx]; ++kx) v = v + r[kx];
+                    out[(((size_t)(ph * 4 + tap) * cq + (i >> 2)) * cout_pad + o) * 4 + (i & 3)] = v;
+                }
+        }
+    return out;
+}
+
 // eval-mode BatchNorm2d as ATen's CPU inference path evaluates it: y = x * alpha + beta with
 // alpha = gamma * (1 / sqrt(var + eps)), beta = bn_bias - mean * alpha   (fp32 throughout).
 void fold_bn(const float* gamma, const float* bbeta, const float* mean, const float* var, int c, int c_pad,
@@ -90,6 +117,7 @@ struct DevLayer {       // one MFMA convolution's parameters on the device
     float* w = nullptr;
     float* w_wino = nullptr;   // 3x3 + BN layers only
     float* w_wino2 = nullptr;  // 3x3 + BN layers only
+    float* w_ups2 = nullptr;   // 3x3 + BN layers that read a x2 up-sampled input only
     float* bias = nullptr;
     float* alpha = nullptr;
     float* beta = nullptr;
@@ -106,6 +134,7 @@ void free_layer(DevLayer& l) {
     if (l.w) (void)hipFree(l.w);
     if (l.w_wino) (void)hipFree(l.w_wino);
     if (l.w_wino2) (void)hipFree(l.w_wino2);
+    if (l.w_ups2) (void)hipFree(l.w_ups2);
     if (l.bias) (void)hipFree(l.bias);
     if (l.alpha) (void)hipFree(l.alpha);
     if (l.beta) (void)hipFree(l.beta);
@@ -118,7 +147,7 @@ struct HostConv {
     const float* g; const float* be; const float* mu; const float* var;   // null when no BN follows
 };
 
-int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out) {
+int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out, bool ups_input = false) {
     DevLayer l;
     l.cin = cin; l.cout = cout; l.ks = ks;
     l.cout_pad = dcx_conv_cout_pad(cout);
@@ -133,6 +162,7 @@ int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out) {
         if (rc == 0) rc = upload(be, &l.beta);
         if (rc == 0 && ks == 3) rc = upload(pack_conv_wino(h.w, cout, cin, l.cout_pad), &l.w_wino);
         if (rc == 0 && ks == 3) rc = upload(pack_conv_wino2(h.w, cout, cin, l.cout_pad), &l.w_wino2);
+        if (rc == 0 && ks == 3 && ups_input) rc = upload(pack_conv_ups2(h.w, cout, cin, l.cout_pad), &l.w_ups2);
     }
     if (rc != 0) { free_layer(l); return rc; }
     *out = l;
@@ -229,7 +259,7 @@ DcxConvArgs conv_args(const DevLayer& l, const float* in, int n, int in_cq_total
                       int ups, int pad, float* out, int out_cq_total, const int* n_limit) {
     DcxConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.w_wino2 = l.w_wino2; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
+    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.w_wino2 = l.w_wino2; a.w_ups2 = l.w_ups2; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
     a.n_limit = n_limit;
     a.n = n; a.in_cq_total = in_cq_total; a.in_cq_off = in_cq_off; a.cin = l.cin;
     a.hin = hin; a.win = win; a.ups = ups; a.pad = pad;
@@ -414,8 +444,9 @@ extern "C" int dcx_refiner_create(dcx_refiner** out, const float* const* t, int 
     static const int cin[9] = {64, 64, 128, 128, 128, 128, 128, 128, 64};
     static const int cout[9] = {64, 128, 128, 128, 128, 128, 128, 64, 64};
     int rc = make_first_layer(hc(0), &r->first);
-    for (int i = 0; rc == 0 && i < 9; ++i) rc = make_layer(hc(6 + 6 * i), cin[i], cout[i], 3, &r->mid[i]);
-    if (rc == 0) rc = make_layer(hc(60), 64, 64, 3, &r->head_a);
+    // conv4a (i = 5), conv5a (i = 7) and convPa read the x2 up-sampled output of the layer before them (refinenet.py:66,72,78)
+    for (int i = 0; rc == 0 && i < 9; ++i) rc = make_layer(hc(6 + 6 * i), cin[i], cout[i], 3, &r->mid[i], i == 5 || i == 7);
+    if (rc == 0) rc = make_layer(hc(60), 64, 64, 3, &r->head_a, true);
     if (rc == 0) {
         std::vector<float> hw(t[66], t[66] + 64);   // convPb.weight (1,64,1,1)
         rc = upload(hw, &r->head_w);
@@ -486,7 +517,7 @@ extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches
         DcxConvArgs a = conv_args(rf->head_a, src, p, 16, 0, 32, 32, 1, 1, nullptr, 16, lim);
         a.head_w = rf->head_w; a.head_b = rf->head_b; a.heat = d_heat;
         a.part_val = (float*)(ws + L.pval); a.part_idx = (int*)(ws + L.pidx);
-        heat_tiles = dcx_conv_heat_tiles(a.ho, a.wo);
+        heat_tiles = dcx_conv_heat_tiles(a.ho, a.wo, a.w_ups2 != nullptr ? 1 : 0);
         if (heat_tiles <= 0 || heat_tiles > kRefTiles) return DCX_E_SHAPE;
         rc = dcx_launch_conv_mfma(a, 3, 0, DCX_EPI_HEAT, s);
         if (rc) return rc;
@@ -605,7 +636,7 @@ extern "C" int dcx_conv_layer(const float* d_in, int n, int cin, int hin, int wi
     if (bn != (relu != 0)) return DCX_E_ARG;   // kernels implement conv+BN+ReLU or raw conv+bias
     if (bn && (!h_be || !h_mu || !h_var)) return DCX_E_ARG;
     DevLayer l;
-    int rc = make_layer(HostConv{h_w, h_b, h_g, h_be, h_mu, h_var}, cin, cout, ksize, &l);
+    int rc = make_layer(HostConv{h_w, h_b, h_g, h_be, h_mu, h_var}, cin, cout, ksize, &l, ups != 0);
     if (rc) return rc;
     DcxConvArgs a;
     if (ksize == 1) {

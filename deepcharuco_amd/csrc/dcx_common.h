@@ -27,6 +27,8 @@ struct DcxConvArgs {
     const float* w;        // packed [ks*ks][cin/4][cout_pad][4]   (4 = cin % 4)
     const float* w_wino;   // nullable; 3x3 + BN layers: F(2,3)-transformed weights [ky*4 + p][cin/4][cout_pad][4] (dcx_conv_wino.h)
     const float* w_wino2;  // nullable; same layers: F(2x2,3x3)-transformed weights [xi*4 + nu][cin/4][cout_pad][4] (dcx_conv_wino2.h)
+    const float* w_ups2;   // nullable; 3x3 + BN layers read through a nearest x2 up-sampling: the four phases' pre-summed 2x2 kernels
+                           // [phase][tap][cin/4][cout_pad][4] (dcx_conv_mfma.h, PH variant)
     const float* bias;     // [cout_pad]
     const float* alpha;    // [cout_pad]  gamma / sqrt(var + eps)
     const float* beta;     // [cout_pad]  bn_beta - mean * alpha
@@ -59,8 +61,9 @@ struct DcxConvArgs {
 int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t stream);
 // Rounds cout up to what dcx_launch_conv_mfma needs for cout_pad.
 int dcx_conv_cout_pad(int cout);
-// Number of spatial tiles the DCX_EPI_HEAT launch will use for (ho, wo) (size of part_* per image).
-int dcx_conv_heat_tiles(int ho, int wo);
+// Number of partial arg-max slots per image the DCX_EPI_HEAT launch will write for an (ho, wo) heat-map (size of part_*);
+// ups: the layer reads its input through a x2 up-sampling (the phase variant then writes 4 slots per low-resolution tile).
+int dcx_conv_heat_tiles(int ho, int wo, int ups);
 
 // ---------------------------------------------------------------------------------------
 // everything else (dcx_misc.hip)

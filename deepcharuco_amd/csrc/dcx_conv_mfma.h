@@ -44,10 +44,19 @@ typedef unsigned int dcx_u32x4 __attribute__((ext_vector_type(4)));
 
 #define DCX_CCH 16  // input channels per LDS chunk ("unit" of the software pipeline)
 
-template <int WM_, int WN_, int MT_, int NT_, int TH_, int TW_, int KS_, bool POOL_, int EPI_>
+// PH_ ("phase" variant, KS_ = 2): a 3x3 convolution (pad 1) over a nearest-x2 UP-SAMPLED input, computed on the low-resolution
+// tensor.  Up-sampling repeats every input pixel 2x2, so the 3x3 window of output pixel (2y+a, 2x+b) only ever sees a 2x2
+// block of distinct low-resolution pixels: rows {y-1: ky=0 | y: ky=1,2} for a = 0, {y: ky=0,1 | y+1: ky=2} for a = 1, and
+// the same for columns.  Each of the four output phases (a, b) is therefore a 2x2 convolution with top/left padding
+// (1-a, 1-b) and pre-summed weights (dcx_api.hip: pack_conv_ups2) -- 4 multiply-adds per output instead of 9, with NO
+// transform of activations or outputs (the 2-D Winograd kernel reaches the same 4/9 with an input and an output
+// transform whose vector-ALU work the fp32 MFMA cannot overlap).  A work item is (image, cout tile, phase, LOW-RES tile);
+// its outputs are stored at stride 2.  Summation order: the direct kernel's (chunk / tap dy-major over the 2x2 / s / j).
+template <int WM_, int WN_, int MT_, int NT_, int TH_, int TW_, int KS_, bool POOL_, int EPI_, bool PH_ = false>
 struct DcxConvCfg {
     static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, TH = TH_, TW = TW_, KS = KS_;
     static constexpr bool POOL = POOL_;
+    static constexpr bool PH = PH_;
     static constexpr int EPI = EPI_;
     static constexpr int NTHREADS = WM * WN * 64;
     static constexpr int COUT_TILE = WM * MT * 32;
@@ -77,6 +86,8 @@ struct DcxConvCfg {
     static_assert(EPI != DCX_EPI_HEAT || (WM == 1 && !POOL), "heat epilogue needs all couts in one wave row");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
     static_assert(STEPS >= 2, "pipeline needs two k-steps per unit");
+    static_assert(!PH || (KS == 2 && !POOL && EPI != DCX_EPI_RAW), "phase variant: 2x2 taps, BN+ReLU (or head) epilogue, no pooling");
+    static_assert(PH || KS != 2, "2x2 taps exist only as the phase variant");
 };
 
 __device__ __forceinline__ float4 dcx_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -108,8 +119,9 @@ __device__ __forceinline__ float4 dcx_relu_quad_max(float4 v) {
     return v;
 }
 
-struct DcxItem {   // one work item = (image, cout tile, spatial tile); all fields wave-uniform
+struct DcxItem {   // one work item = (image, cout tile, [phase,] spatial tile); all fields wave-uniform
     int n, ct, ty, tx;
+    int ph;            // phase variant only: output phase 2a + b
 };
 
 // Persistent, software-pipelined kernel.
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     const int n_ct = a.cout_pad / C::COUT_TILE;
     int n_eff = a.n;
     if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
-    const int total = n_eff * n_ct * tiles;     // images are the slowest index: skipped ones are at the end
+    const int total = n_eff * n_ct * tiles * (C::PH ? 4 : 1);     // images are the slowest index: skipped ones are at the end
     int w = blockIdx.x;
     if (w >= total) return;
     if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
@@ -152,10 +164,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         DcxItem it;
         it.tx = wi % a.tiles_x; wi /= a.tiles_x;
         it.ty = wi % a.tiles_y; wi /= a.tiles_y;
+        it.ph = 0;
+        if (C::PH) { it.ph = wi & 3; wi >>= 2; }       // the four phases of a tile are neighbours in the item list (same input)
         it.ct = wi % n_ct;
         it.n = wi / n_ct;
         return it;
     };
+    // top / left padding of an item: the layer's, or (phase variant) 1 - a / 1 - b
+    auto pad_y = [&](const DcxItem& it) { return C::PH ? 1 - (it.ph >> 1) : a.pad; };
+    auto pad_x = [&](const DcxItem& it) { return C::PH ? 1 - (it.ph & 1) : a.pad; };
 
     const int hl = a.hin << a.ups, wl = a.win << a.ups;  // logical (up-sampled) input size
 
@@ -198,9 +215,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     // buffer addressing: voffset = per-lane constant, soffset = uniform (unit base + step offset) in an SGPR,
     // the m-tile stride (512 B) goes into the instruction's immediate field -> no VALU per load
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w), (short)0, (int)((unsigned)KS * KS * w_tap_stride), 0x00020000);
-    auto unit_wbase = [&](const DcxItem& it, int c) {
-        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u;
+        const_cast<float*>(C::PH ? a.w_ups2 : a.w), (short)0, (int)((unsigned)(C::PH ? 4 : 1) * KS * KS * w_tap_stride), 0x00020000);
+    auto unit_wbase = [&](const DcxItem& it, int c) {      // phase variant: [phase][tap][cin/4][cout_pad][4]
+        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u + (C::PH ? (unsigned)it.ph * (KS * KS) * w_tap_stride : 0u);
     };
     auto load_a = [&](unsigned wbase, int step, float4 (&dst)[MT]) {
         const int tap = step / (DCX_CCH / 8);
@@ -242,14 +259,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     auto unit_rsrc = [&](const DcxItem& it, int c) {
         // element (row (ty*TH>>ups) - pad, col (tx*TW>>ups) - pad) of the unit's first channel quad; for tiles on the
         // top/left border this points before the tensor, but those lanes are masked and never dereferenced
-        const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
+        const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - pad_y(it)) * a.win + (((it.tx * C::TW) >> a.ups) - pad_x(it));
         const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
                                     + tile_off) * 4;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
     };
     // a tile is "interior" when its whole halo lies inside the (logical) image: no predicate needed at all
     auto tile_interior = [&](const DcxItem& it) {
-        const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
+        const int sy0 = it.ty * C::TH - pad_y(it), sx0 = it.tx * C::TW - pad_x(it);
         return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + C::HW <= wl;
     };
     auto stage_off = [&](int sy0, int sx0, int pi) {   // general (border / overhanging tile) form
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         load_a(wb, 0, a_c0);
         load_a(wb, 1, a_c1);
         const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(cur, 0);
-        const int sy0 = cur.ty * C::TH - a.pad, sx0 = cur.tx * C::TW - a.pad;
+        const int sy0 = cur.ty * C::TH - pad_y(cur), sx0 = cur.tx * C::TW - pad_x(cur);
         float4 v[ITER];
 #pragma unroll
         for (int pi = 0; pi < ITER; ++pi) v[pi] = stage_fetch(r0, stage_off(sy0, sx0, pi));
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[5 + 3 * u] = __builtin_amdgcn_s_memtime();
 
         const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
-        const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
+        const int nsy0 = nxt.ty * C::TH - pad_y(nxt), nsx0 = nxt.tx * C::TW - pad_x(nxt);
         const unsigned wb_cur = unit_wbase(cur, c);
         const unsigned wb_nxt = unit_wbase(nxt, cn);
         // Software pipeline of one unit (everything below is ONE basic block, fully unrolled):
@@ -427,6 +444,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                 int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
                 bool ok = qok[nt] && sy < a.ho && sx < a.wo;
                 if (C::POOL) { ok = ok && (P4 || (l31 & 3) == 0); sy >>= 1; sx >>= 1; }
+                if (C::PH) {   // (sy, sx) is a low-resolution pixel: this item produces its phase-(a, b) output
+                    ok = qok[nt] && 2 * sy < a.ho && 2 * sx < a.wo;
+                    sy = 2 * sy + (cur.ph >> 1); sx = 2 * sx + (cur.ph & 1);
+                }
                 pix_ok[nt] = ok;
                 lane_off[nt] = ((unsigned)half * plane + (unsigned)(sy * ws + sx)) * 16u;
             }
@@ -496,8 +517,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                 for (int nt = 0; nt < NT; ++nt) {
                     const float tot = hsum[nt] + __shfl_xor(hsum[nt], 32);   // the two half-waves hold disjoint couts
                     const float logit = tot + a.head_b;
-                    const int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
-                    const bool ok = qok[nt] && sy < a.ho && sx < a.wo;
+                    int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
+                    bool ok = qok[nt] && sy < a.ho && sx < a.wo;
+                    if (C::PH) {
+                        ok = qok[nt] && 2 * sy < a.ho && 2 * sx < a.wo;
+                        sy = 2 * sy + (cur.ph >> 1); sx = 2 * sx + (cur.ph & 1);
+                    }
                     if (ok) {
                         const int idx = sy * a.wo + sx;
                         if (a.heat != nullptr && half == 0) a.heat[((size_t)n * a.ho + sy) * a.wo + sx] = logit;
@@ -521,8 +546,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                         const int oi = red_i[wv];
                         if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
                     }
-                    a.part_val[(size_t)n * tiles + cur.ty * a.tiles_x + cur.tx] = best;
-                    a.part_idx[(size_t)n * tiles + cur.ty * a.tiles_x + cur.tx] = besti;
+                    const size_t slot = (size_t)n * (tiles * (C::PH ? 4 : 1)) + (size_t)cur.ph * tiles + cur.ty * a.tiles_x + cur.tx;
+                    a.part_val[slot] = best;
+                    a.part_idx[slot] = besti;
                 }
             }
         }
@@ -559,8 +585,14 @@ template <class C>
 static int dcx_conv_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     a.tiles_x = (a.wo + C::TW - 1) / C::TW;
     a.tiles_y = (a.ho + C::TH - 1) / C::TH;
+    if (C::PH) {      // tiles are cut in the LOW-RESOLUTION image the kernel reads; ho x wo stays the (x2) output size
+        if (a.ups != 1 || a.pad != 1 || a.w_ups2 == nullptr || a.ho != 2 * a.hin || a.wo != 2 * a.win) return DCX_E_SHAPE;
+        a.tiles_x = (a.win + C::TW - 1) / C::TW;
+        a.tiles_y = (a.hin + C::TH - 1) / C::TH;
+        a.ups = 0;    // addresses are low-resolution pixels
+    }
     if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0) return DCX_E_SHAPE;
-    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
+    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y * (C::PH ? 4 : 1);
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
     const int occ_env = dcx_occupancy_override();                      // tuning knob (DCX_OCC), 0 = default
     const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);   // persistent workgroups

@@ -14,35 +14,43 @@ struct CfgEntry {
     int inlane;   // pooled layout with the 2x2 window inside one lane (MT=1, NT=4): no cross-lane max
     int group;    // images per work item (2-D Winograd grouped tiles for small maps); 1 otherwise
     int wino;     // 1: 1-D Winograd F(2,3) kernel (dcx_conv_wino.h), 2/3 of the MFMAs; 2: 2-D F(2x2,3x3) (dcx_conv_wino2.h), 4/9
+    int ups2;     // 1: phase variant of the direct kernel for 3x3 layers that read a x2 up-sampled input (4/9 of the MFMAs, no
+                  //    transform): th x tw is a LOW-RESOLUTION tile, every tile is four work items (dcx_conv_mfma.h)
     int (*launch)(DcxConvArgs, hipStream_t);
     const char* name;
 };
 
 #define DCX_CFG(WM, WN, MT, NT, TH, TW, KS, POOL, EPI)                                              \
-    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT, ((POOL) != 0 && MT == 1 && NT == 4) ? 1 : 0, 1, 0, \
+    { WM * MT * 32, WN * NT * 32, TH, TW, KS, POOL, EPI, MT * NT, ((POOL) != 0 && MT == 1 && NT == 4) ? 1 : 0, 1, 0, 0, \
       &dcx_conv_launch_cfg<DcxConvCfg<WM, WN, MT, NT, TH, TW, KS, (POOL) != 0, EPI>>,                 \
       "dcx_conv_mfma_kernel<DcxConvCfg<" #WM "," #WN "," #MT "," #NT "," #TH "," #TW "," #KS "," #POOL "," #EPI ">>" }
 
+// phase variant (x2 up-sampled input): the entry's ks stays 3 (the LAYER is 3x3), the kernel runs 2x2 taps
+#define DCX_PCFG(WM, WN, MT, NT, TH, TW, EPI)                                                          \
+    { WM * MT * 32, WN * NT * 32, TH, TW, 3, 0, EPI, MT * NT, 0, 1, 0, 1,                                   \
+      &dcx_conv_launch_cfg<DcxConvCfg<WM, WN, MT, NT, TH, TW, 2, false, EPI, true>>,                       \
+      "dcx_conv_mfma_kernel<DcxConvCfg<" #WM "," #WN "," #MT "," #NT "," #TH "," #TW ",2,0," #EPI ",PH>>" }
+
 #define DCX_WCFG(WM, WN, TH, TW, POOL)                                                                \
-    { WM * 32, WN * 64, TH, TW, 3, POOL, DCX_EPI_BNRELU, 4, 0, 1, 1,                                        \
+    { WM * 32, WN * 64, TH, TW, 3, POOL, DCX_EPI_BNRELU, 4, 0, 1, 1, 0,                                     \
       &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, (POOL) != 0>>,                                  \
       "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW "," #POOL ">>" }
 #define DCX_WCFG_HEAT(WM, WN, TH, TW)                                                                  \
-    { WM * 32, WN * 64, TH, TW, 3, 0, DCX_EPI_HEAT, 4, 0, 1, 1,                                             \
+    { WM * 32, WN * 64, TH, TW, 3, 0, DCX_EPI_HEAT, 4, 0, 1, 1, 0,                                          \
       &dcx_conv_wino_launch_cfg<DcxWinoCfg<WM, WN, TH, TW, false, DCX_EPI_HEAT>>,                          \
       "dcx_conv_wino_kernel<DcxWinoCfg<" #WM "," #WN "," #TH "," #TW ",0,DCX_EPI_HEAT>>" }
 
 #define DCX_W2CFG(TH, TW, POOL)                                                                       \
-    { 64, 256, TH, TW, 3, POOL, DCX_EPI_BNRELU, 16, 0, 1, 2,                                                 \
+    { 64, 256, TH, TW, 3, POOL, DCX_EPI_BNRELU, 16, 0, 1, 2, 0,                                              \
       &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, (POOL) != 0>>,                                        \
       "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW "," #POOL ">>" }
 
 #define DCX_W2CFG_G(TH, TW, G)                                                                        \
-    { 64, 256, TH, TW, 3, 0, DCX_EPI_BNRELU, 16, 0, G, 2,                                                   \
+    { 64, 256, TH, TW, 3, 0, DCX_EPI_BNRELU, 16, 0, G, 2, 0,                                                \
       &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, false, DCX_EPI_BNRELU, G>>,                           \
       "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW ",0,DCX_EPI_BNRELU," #G ">>" }
 #define DCX_W2CFG_HEAT(TH, TW)                                                                        \
-    { 64, 256, TH, TW, 3, 0, DCX_EPI_HEAT, 16, 0, 1, 2,                                                      \
+    { 64, 256, TH, TW, 3, 0, DCX_EPI_HEAT, 16, 0, 1, 2, 0,                                                   \
       &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, false, DCX_EPI_HEAT>>,                                \
       "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW ",0,DCX_EPI_HEAT>>" }
 
@@ -93,7 +101,19 @@ const CfgEntry kCfgs[] = {
     DCX_W2CFG(8, 32, 1),
     DCX_W2CFG_HEAT(16, 16),
     DCX_W2CFG_G(8, 8, 4),     // four whole 8x8 maps (RefineNet after its pool) per work item
+    // phase variant for the layers behind RefineNet's three x2 up-samplings (conv4a 8->16, conv5a 16->32, convPa 32->64):
+    // low-resolution tiles 8x32 / 16x16 (A layout, 64 couts x 256 px) and 8x8 (S layout)
+    DCX_PCFG(1, 4, 2, 2, 8, 32, DCX_EPI_BNRELU),
+    DCX_PCFG(1, 4, 2, 2, 16, 16, DCX_EPI_BNRELU),
+    DCX_PCFG(2, 2, 1, 1, 8, 8, DCX_EPI_BNRELU),
+    DCX_PCFG(1, 4, 2, 2, 8, 32, DCX_EPI_HEAT),
 };
+
+int dcx_ups2_enabled() {   // on by default; DCX_UPS2=0 keeps up-sampled layers on the Winograd / direct kernels (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_UPS2"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v;
+}
 
 int dcx_wino2_enabled() {   // on by default; DCX_WINO2=0 keeps the 1-D Winograd / direct kernels (A/B runs)
     static int v = -1;
@@ -136,7 +156,7 @@ int dcx_big_tiles_disabled() {
 // accounted for -- plus ~520 cycles per 16-channel unit (barrier, first LDS wait, scalar bookkeeping) and an epilogue
 // of ~40 (60 pooled) cycles per accumulator register.  Big tiles win when there is plenty of work (less halo, fewer
 // units), the 64x64 S tile when a launch has few items (bs=1, 30x40 maps) or would leave CUs idle in the last round.
-const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int pool, int epi, int allow_group = 1) {
+const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int pool, int epi, int allow_group = 1, int ups = 0) {
     const CfgEntry* best = nullptr;
     double best_cost = 0.0;
     const int n_cu = dcx_device_cu_count();
@@ -146,7 +166,7 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
     if (force != nullptr && force[0] != 0) {
         for (const CfgEntry& c : kCfgs)
             if (strcmp(c.name, force) == 0 && c.ks == ks && c.pool == pool && c.epi == epi && cout_pad % c.cout_tile == 0 &&
-                (c.group == 1 || (allow_group && ho <= c.th && wo <= c.tw)))
+                (c.group == 1 || (allow_group && ho <= c.th && wo <= c.tw)) && (!c.ups2 || ups == 1))
                 return &c;
     }
     for (const CfgEntry& c : kCfgs) {
@@ -156,6 +176,17 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         if (c.wino == 1 && (!dcx_wino_enabled() || dcx_deterministic_enabled())) continue;
         if (c.wino == 2 && (!dcx_wino2_enabled() || dcx_deterministic_enabled())) continue;
         if (c.group > 1 && (!allow_group || ho > c.th || wo > c.tw)) continue;   // grouped tiles: whole small maps only
+        if (c.ups2) {      // phase variant: only for layers reading a x2 up-sampled input; tiles are low-resolution, x4 items,
+                           // 8 k-steps (4 taps x 2) per 16-channel unit
+            if (ups != 1 || !dcx_ups2_enabled() || dcx_deterministic_enabled()) continue;
+            const long lt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);
+            const double items_p = (double)n * (cout_pad / c.cout_tile) * lt * 4;
+            const int units_p = cin / DCX_CCH;
+            const double item_cost_p = (double)units_p * 8 * (4 * c.acc_tiles) * 64.0 + units_p * 520.0 + c.acc_tiles * 16 * 40.0;
+            const double cost_p = (double)(((long)items_p + n_cu - 1) / n_cu) * item_cost_p;
+            if (best == nullptr || cost_p < best_cost) { best_cost = cost_p; best = &c; }
+            continue;
+        }
         const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
         if (c.cap > 256 && (dcx_big_tiles_disabled() || (double)ho * wo / ((double)tiles * c.cap) < 0.999)) continue;
         const double items = (double)((n + c.group - 1) / c.group) * (cout_pad / c.cout_tile) * tiles;
@@ -200,6 +231,11 @@ hipEvent_t prof_event() {
 // which instantiation the cost model picks for a launch shape (no GPU needed; used by tests and tools)
 extern "C" const char* dcx_conv_pick_name(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi) {
     const CfgEntry* c = pick(n, cin, ho, wo, dcx_conv_cout_pad(cout), ks, pool, epi);
+    return c ? c->name : "";
+}
+// same for a layer that reads its input through a nearest x2 up-sampling (ho x wo = the up-sampled output size)
+extern "C" const char* dcx_conv_pick_name_ups(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi, int ups) {
+    const CfgEntry* c = pick(n, cin, ho, wo, dcx_conv_cout_pad(cout), ks, pool, epi, ups == 0, ups);
     return c ? c->name : "";
 }
 
@@ -288,9 +324,11 @@ int dcx_occupancy_override() {
     return v;
 }
 
-int dcx_conv_heat_tiles(int ho, int wo) {
-    const CfgEntry* c = pick(1 << 20, 64, ho, wo, 64, 3, 0, DCX_EPI_HEAT);
-    return c ? ((ho + c->th - 1) / c->th) * ((wo + c->tw - 1) / c->tw) : 0;
+int dcx_conv_heat_tiles(int ho, int wo, int ups) {
+    const CfgEntry* c = pick(1 << 20, 64, ho, wo, 64, 3, 0, DCX_EPI_HEAT, 1, ups);
+    if (c == nullptr) return 0;
+    if (c->ups2) return 4 * ((ho / 2 + c->th - 1) / c->th) * ((wo / 2 + c->tw - 1) / c->tw);
+    return ((ho + c->th - 1) / c->th) * ((wo + c->tw - 1) / c->tw);
 }
 
 int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t stream) {
@@ -300,7 +338,8 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
     if (pool && ((a.ho | a.wo) & 1)) return DCX_E_SHAPE;
     // the fused-head launch must use the tiling dcx_conv_heat_tiles() sized part_val / part_idx for
     const CfgEntry* c = pick(epi == DCX_EPI_HEAT ? (1 << 20) : a.n, a.cin, a.ho, a.wo, a.cout_pad, ks, pool, epi,
-                             a.ups == 0 && a.pad == 1);   // grouped tiles: same-size convolutions read without up-sampling
+                             a.ups == 0 && a.pad == 1,    // grouped tiles: same-size convolutions read without up-sampling
+                             (a.ups == 1 && a.pad == 1 && ks == 3 && a.w_ups2 != nullptr) ? 1 : 0);
     if (c == nullptr) return DCX_E_SHAPE;
     if (!g_prof || (g_prof_filter >= 0 && g_prof_filter != (int)(c - kCfgs))) return c->launch(a, stream);
     ProfRec r;

@@ -175,6 +175,8 @@ int dcx_last_timings(float* h_ms4);
 /* name of the kernel instantiation the tile cost model selects for a launch shape (host only, no GPU needed);
  * epi: 0 = BN+ReLU, 1 = raw (1x1 heads), 2 = RefineNet head; "" when no instantiation fits */
 const char* dcx_conv_pick_name(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi);
+/* same for a layer whose input is read through a nearest x2 up-sampling (ho x wo = output size = 2 x the stored input) */
+const char* dcx_conv_pick_name_ups(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi, int ups);
 
 /* ---- deterministic mode -------------------------------------------------------------------
  * By default the launcher picks, per layer and launch size, between three kernel families (direct implicit GEMM, 1-D

@@ -187,3 +187,48 @@ void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, c
                         }
                 }
 }
+
+/* 3x3 (pad 1) + BN + ReLU over a nearest-x2 UP-SAMPLED input through the phase variant of the direct kernel
+ * (deepcharuco_amd/csrc/dcx_conv_mfma.h, PH): x is the LOW-RESOLUTION input [n][cin][h][w], y is [n][cout][2h][2w].
+ *   output (2Y+a, 2X+b): acc = 0; for chunk c0 / tap (dy, dx) in 2x2 (dy-major) / s / j / k:
+ *       acc = fmaf(weff[a][b][dy][dx][ci], x[ci][Y - 1 + a + dy][X - 1 + b + dx] (0 outside), acc),  ci = c0 + 8s + 4k + j
+ *   weff = the 3x3 weights summed over the kernel rows / columns that fall on the same low-resolution pixel: rows
+ *   a = 0: dy 0 <- {0}, dy 1 <- {1, 2};  a = 1: dy 0 <- {0, 1}, dy 1 <- {2};  columns alike with b;  fp32, rows first, then
+ *   columns, left to right (dcx_api.hip: pack_conv_ups2).
+ *   y = max(fmaf(acc, alpha, fmaf(bias, alpha, beta)), 0) */
+void dcx_oracle_conv_ups2_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                                const float* alpha, const float* beta, int cout, float* y) {
+    static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};
+    const int ho = 2 * h, wo = 2 * w;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < n; ++b)
+        for (int co = 0; co < cout; ++co)
+            for (int oy = 0; oy < ho; ++oy)
+                for (int ox = 0; ox < wo; ++ox) {
+                    const int pa = oy & 1, pb = ox & 1, Y = oy >> 1, X = ox >> 1;
+                    float acc = 0.0f;
+                    for (int c0 = 0; c0 < cin; c0 += 16)
+                        for (int tap = 0; tap < 4; ++tap) {
+                            const int dy = tap >> 1, dx = tap & 1;
+                            const int iy = Y - 1 + pa + dy, ix = X - 1 + pb + dx;
+                            const int inb = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                            for (int s = 0; s < 2; ++s)
+                                for (int j = 0; j < 4; ++j)
+                                    for (int k = 0; k < 2; ++k) {
+                                        const int ci = c0 + 8 * s + 4 * k + j;
+                                        const float* g = wt + ((size_t)co * cin + ci) * 9;
+                                        float r[3];
+                                        for (int kx = 0; kx < 3; ++kx) {
+                                            r[kx] = g[lo[pa][dy] * 3 + kx];
+                                            for (int ky = lo[pa][dy] + 1; ky <= hi[pa][dy]; ++ky) r[kx] = r[kx] + g[ky * 3 + kx];
+                                        }
+                                        float wv = r[lo[pb][dx]];
+                                        for (int kx = lo[pb][dx] + 1; kx <= hi[pb][dx]; ++kx) wv = wv + r[kx];
+                                        const float xv = inb ? x[(((size_t)b * cin + ci) * h + iy) * w + ix] : 0.0f;
+                                        acc = fmaf(wv, xv, acc);
+                                    }
+                        }
+                    y[(((size_t)b * cout + co) * ho + oy) * wo + ox] =
+                        fmaxf(fmaf(acc, alpha[co], fmaf(bias[co], alpha[co], beta[co])), 0.0f);
+                }
+}

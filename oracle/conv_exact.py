@@ -27,8 +27,22 @@ def lib():
 def conv_exact(x, wt, bias, bn=None, pad=1, ups=False, pool=False, wino=False):
     """x NCHW float32; bn = (gamma, beta, mean, var) or None (raw).  Returns NCHW float32.
     wino=True: the summation order of the 1-D Winograd F(2,3) kernel, wino=2: of the 2-D F(2x2,3x3) kernel
-    (3x3 + BN layers only)."""
+    (3x3 + BN layers only); wino=3: the phase variant of the direct kernel (3x3 pad 1 + BN over an up-sampled input)."""
     x = np.ascontiguousarray(x, np.float32)
+    if wino == 3:
+        assert ups and bn is not None and pad == 1 and not pool
+        wt = np.ascontiguousarray(wt, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        n, cin, h, w = x.shape
+        cout = wt.shape[0]
+        assert wt.shape[2] == 3 and cin % 16 == 0
+        y = np.empty((n, cout, 2 * h, 2 * w), np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        g, be, mu, var = [np.ascontiguousarray(t, np.float32) for t in bn]
+        alpha, beta = np.empty(cout, np.float32), np.empty(cout, np.float32)
+        lib().dcx_oracle_fold_bn(p(g), p(be), p(mu), p(var), cout, p(alpha), p(beta))
+        lib().dcx_oracle_conv_ups2_exact(p(x), n, cin, h, w, p(wt), p(bias), p(alpha), p(beta), cout, p(y))
+        return y
     if ups:
         x = np.ascontiguousarray(x.repeat(2, axis=2).repeat(2, axis=3))
     wt = np.ascontiguousarray(wt, np.float32)

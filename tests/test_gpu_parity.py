@@ -113,6 +113,11 @@ def _conv_layer(x_nchw, w, b, bn, pad, ups, pool, ks=3):
     return out
 
 
+def _family(kernel_name):
+    """Which exact-order restatement (oracle/conv_exact.c) a kernel instantiation follows."""
+    return 3 if ",PH>>" in kernel_name else 2 if "wino2" in kernel_name else 1 if "wino" in kernel_name else 0
+
+
 def _conv_ref(x, w, b, bn, pad, ups, pool):
     import torch.nn.functional as F
     x = x.cpu()
@@ -143,6 +148,8 @@ CONV_CASES = [
     ("C_8x8", 5, 128, 128, 8, 8, 1, 0, 0, 3, True),
     ("B_8x16_ups", 3, 128, 128, 8, 8, 1, 1, 0, 3, True),
     ("A_8x32_ups_128to64", 2, 128, 64, 16, 16, 1, 1, 0, 3, True),
+    ("P_ups_32x32_64to64", 3, 64, 64, 32, 32, 1, 1, 0, 3, True),
+    ("P_ups_partial_10x12", 2, 64, 64, 10, 12, 1, 1, 0, 3, True),
     ("k1_raw_65", 2, 256, 65, 30, 40, 0, 0, 0, 1, False),
     ("k1_raw_17", 2, 256, 17, 6, 9, 0, 0, 0, 1, False),
 ]
@@ -185,10 +192,9 @@ def test_conv_layer_bit_exact_vs_c_restatement(dev, case):
               torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
     got = _conv_layer(x.to(dev), wt, b, bn, pad, ups, pool, ks).cpu().numpy()
     ho, wo = (h << ups) + 2 * pad - (ks - 1), (w << ups) + 2 * pad - (ks - 1)
-    picked = _lib.lib().dcx_conv_pick_name(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1).decode()
+    picked = _lib.lib().dcx_conv_pick_name_ups(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1, int(ups)).decode()
     ref = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
-                     pad=pad, ups=bool(ups), pool=bool(pool),
-                     wino=2 if "wino2" in picked else 1 if "wino" in picked else 0)   # each kernel has its own order
+                     pad=pad, ups=bool(ups), pool=bool(pool), wino=_family(picked))   # each kernel family has its own order
     nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     _report(f"conv_layer_bitexact/{name}", dict(kernel=picked[picked.find("dcx_conv_") + 9:], mismatching_elements=nbad,
                                                 max_abs=float(np.abs(got - ref).max())))
@@ -227,10 +233,10 @@ def test_every_conv_instantiation_bit_exact(dev, monkeypatch):
             if "HEAT" in cfg:
                 continue      # the fused RefineNet head has its own entry point (covered by the refiner tests)
             monkeypatch.setenv("DCX_FORCE_CFG", cfg)
-            if L.dcx_conv_pick_name(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1).decode() != cfg:
-                continue      # this instantiation cannot run this layer (kernel size / pooling / cout tile)
+            if L.dcx_conv_pick_name_ups(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1, int(ups)).decode() != cfg:
+                continue      # this instantiation cannot run this layer (kernel size / pooling / cout tile / up-sampling)
             got = _conv_layer(x.to(dev), wt, b, bn, pad, ups, pool, ks).cpu().numpy()
-            wino = 2 if "wino2" in cfg else 1 if "wino" in cfg else 0
+            wino = _family(cfg)
             if wino not in refs:
                 refs[wino] = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
                                         pad=pad, ups=bool(ups), pool=bool(pool), wino=wino)
