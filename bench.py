@@ -272,11 +272,13 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         # The Winograd kernels execute only part of a layer's ALGORITHMIC multiply-adds on the matrix cores (1-D F(2,3):
         # 2/3; 2-D F(2x2,3x3): 4/9), so `achieved` (algorithmic FLOP / time, what the contract asks for) can exceed the
         # fp32-MFMA peak; `executed_*` is what the matrix pipe really ran.
-        scale_of = lambda nm: 4.0 / 9.0 if "wino2" in nm else 2.0 / 3.0 if "wino" in nm else 1.0
+        # (",PH>>": the phase variant for up-sampled inputs executes 4 of the 9 taps' worth of MACs, with pre-summed weights)
+        scale_of = lambda nm: 4.0 / 9.0 if ("wino2" in nm or ",PH>>" in nm) else 2.0 / 3.0 if "wino" in nm else 1.0
         exec_scale = scale_of(kname(dom_id))
         conv_exec = sum(a[0] * scale_of(kname(k)) for k, a in full.items())
         algo = ("winograd F(2x2,3x3): 4/9 of the algorithmic MACs are executed" if "wino2" in kname(dom_id)
                 else "winograd F(2,3) along x: 2/3 of the algorithmic MACs are executed" if "wino" in kname(dom_id)
+                else "phase-decomposed 3x3 over a x2 up-sampled input: 4/9 of the algorithmic MACs are executed" if ",PH>>" in kname(dom_id)
                 else "direct implicit GEMM")
         roofline = {"bound": "mfma", "kernel": kname(dom_id), "launches": launches, "algorithm": algo,
                     "executed_achieved": round(achieved * exec_scale, 2),

@@ -98,13 +98,21 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
     int n_eff = a.n;
     if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
     const int total = n_eff * n_ct * tiles;
-    int w = blockIdx.x;
-    if (w >= total) return;
+    // XCD-aware item walk (see dcx_conv_wino2.h): block b runs on XCD b % 8 (observed; used for speed only), so the blocks
+    // of one XCD walk one contiguous eighth of the item list and share halos / repeated inputs through their L2
+    int w = blockIdx.x, w_end = total, gstride = gridDim.x;
+    if (a.xcd_walk && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7;
+        const int lo = (int)(((long)total * x) >> 3);
+        w_end = (int)(((long)total * (x + 1)) >> 3);
+        gstride = gridDim.x >> 3;
+        w = lo + (blockIdx.x >> 3);
+    }
+    if (w >= w_end) return;
     if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
         a.clk_probe[0] = __builtin_amdgcn_s_memtime();
         a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
     }
-    const int gstride = gridDim.x;
     const int nch = a.cin / DCX_CCH;
     auto decode = [&](int wi) {
         DcxItem it;
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino_kernel(cons
         int cn = c + 1;
         bool has_next = true;
         if (cn == nch) {
-            if (w + gstride < total) { nxt = decode(w + gstride); cn = 0; }
+            if (w + gstride < w_end) { nxt = decode(w + gstride); cn = 0; }
             else { has_next = false; cn = c; }
         }
         const int buf = u & 1;
@@ -507,6 +515,7 @@ static int dcx_conv_wino_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const int occ_env = dcx_occupancy_override();
     const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);
     const long blocks = items < resident ? items : resident;
+    a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
     static bool attr_set[DCX_MAX_DEVICES] = {};      // the attribute is per device (multi-GPU processes)
     const int dev_i = dcx_current_device();
     if (!attr_set[dev_i]) {

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (mean per launch, per kernel).
 
-HBM bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024.  The factor 2 on FETCH_SIZE is the gfx950
-correction of /opt/skills/guides/MI355X_MICROARCH.md (section HBM): this rocprofv3 tallies the 128-B requests of a wide
-coalesced stream at 64 B.  WRITE_SIZE matched the exact output bytes of the pooled conv kernels and is used as reported.
-usage: python tools/make_pmc_traffic.py <fetch.db> <write.db> > profiles/pmc_traffic.json
+HBM-side bytes per launch = FETCH_SIZE[KB] * 1024 / k + WRITE_SIZE[KB] * 1024, where k is CALIBRATED on a known byte
+count in the kernels' own access pattern (tools/ubench/fetch_calib.hip, third argument = its rocprofv3 --pmc FETCH_SIZE
+result): on gfx950 FETCH_SIZE reports 0.50 of the bytes of a coalesced 16 B/lane stream (the guide's "double it") but 0.91
+of the bytes of the convolution kernels' input staging (288-B row segments starting 16 B before a 256-B boundary,
+buffer_load_dwordx4) -- the blanket x2 of round 1 over-stated their reads by 1.8x.  WRITE_SIZE matched the exact output
+bytes of the pooled conv kernels and is used as reported.  The file is stamped with a hash of the kernel sources it was
+measured on; bench.py ignores it when they have changed.
+usage: python tools/make_pmc_traffic.py <fetch.db> <write.db> <calib.db> > profiles/pmc_traffic.json
 """
 import collections, json, re, sqlite3, sys
 
@@ -40,22 +44,42 @@ def lib_name(rocprof_name):
     f = [x.strip() for x in m.group(1).split(",")]
     f[7] = "1" if f[7] == "true" else "0"
     f[8] = {"0": "DCX_EPI_BNRELU", "1": "DCX_EPI_RAW", "2": "DCX_EPI_HEAT"}[f[8]]
+    if len(f) > 9:      # phase variant: <..., EPI, true> -> the library's "...,EPI,PH"
+        f = f[:9] + (["PH"] if f[9] == "true" else [])
     return "dcx_conv_mfma_kernel<DcxConvCfg<" + ",".join(f) + ">>"
 
 
-def main(fetch_db, write_db):
+KNOWN = {"calib_stream": 1258291200, "calib_tiles<32, 15>": 393154560, "calib_tiles<18, 0>": 1248473088}   # fetch_calib.hip
+
+
+def main(fetch_db, write_db, calib_db):
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepcharuco_amd import _lib
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    cal = per_kernel(calib_db, "FETCH_SIZE")
+    ratio = {}
+    for name, v in cal.items():
+        for key, known in KNOWN.items():
+            if key in name:
+                ratio[key] = v * 1024 / known
+    k = ratio["calib_tiles<32, 15>"]
     out = {}
     for name in f:
         ln = lib_name(name)
         if ln is None or name not in w:
             continue
-        out[ln] = int(2 * f[name] * 1024 + w[name] * 1024)
+        out[ln] = int(f[name] * 1024 / k + w[name] * 1024)
     out["_detail"] = {lib_name(n): {"FETCH_SIZE_KB_reported": round(f[n], 1), "WRITE_SIZE_KB": round(w.get(n, 0), 1)}
                       for n in f if lib_name(n)}
-    out["_note"] = "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB*1024), mean over the launches of separate --pmc passes"
+    out["_calibration"] = {"FETCH_SIZE_reported_over_known_bytes": {kk: round(v, 4) for kk, v in ratio.items()},
+                           "used": "calib_tiles<32, 15> (the conv kernels' staging pattern)"}
+    out["_csrc_sha256"] = _lib.csrc_sha256()
+    out["_note"] = ("bytes per launch = FETCH_SIZE / k + WRITE_SIZE (KB*1024), mean over the launches of separate --pmc passes; "
+                    "FETCH_SIZE excludes what the 256 MB Infinity Cache serves, so a layer whose input was just written can "
+                    "read less than its algorithmic input bytes")
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3])

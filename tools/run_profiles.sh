@@ -14,7 +14,7 @@ if [ "$MODE" = collect ]; then
     (cd "$ROOT" && timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.log" 2>&1; echo "bench exit $?" >> "$OUT/bench.log")
     cd /tmp
     rm -rf "$OUT"/prof_r${R}*
-    B="python $ROOT/bench.py --no-cpu-baseline"
+    B="python $ROOT/bench.py --no-cpu-baseline --no-extras"
     timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}" -o r${R} -- $B --steps 10 --warmup 3 > "$OUT/rocprof.log" 2>&1
     timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_fetch" -o fetch -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_fetch.log" 2>&1
     timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/prof_r${R}_write" -o write -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_write.log" 2>&1
@@ -22,10 +22,19 @@ if [ "$MODE" = collect ]; then
         -d "$OUT/prof_r${R}_sq" -o sq -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_sq.log" 2>&1
     timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE \
         -d "$OUT/prof_r${R}_lds" -o lds -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_lds.log" 2>&1
+    # FETCH_SIZE calibration on known byte counts (tools/ubench/fetch_calib.hip) and the flat-walk A/B of the item order
+    timeout 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_calib" -o calib -- $ROOT/tools/ubench/fetch_calib > "$OUT/calib.log" 2>&1
+    DCX_XCD_WALK=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_fetch_flat" -o fetch -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_fetch_flat.log" 2>&1
+    # bs=1 (the reference's own protocol): per-kernel times
+    timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}_bs1" -o bs1 -- python $ROOT/tools/bs1_loop.py 60 1 > "$OUT/rocprof_bs1.log" 2>&1
     tail -1 "$OUT/bench.log"
 else
     cd "$ROOT"
-    python tools/make_pmc_traffic.py gpurun_out/prof_r${R}_fetch/fetch_results.db gpurun_out/prof_r${R}_write/write_results.db > profiles/pmc_traffic.json
+    python tools/make_pmc_traffic.py gpurun_out/prof_r${R}_fetch/fetch_results.db gpurun_out/prof_r${R}_write/write_results.db gpurun_out/prof_r${R}_calib/calib_results.db > profiles/pmc_traffic.json
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_calib/calib_results.db calib > profiles/r${R}_pmc_fetch_calibration.txt
+    grep "known bytes" gpurun_out/calib.log >> profiles/r${R}_pmc_fetch_calibration.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_fetch_flat/fetch_results.db dcx_ > profiles/r${R}_pmc_fetch_size_flat_walk.txt
+    python tools/rocprof_summary.py gpurun_out/prof_r${R}_bs1/bs1_results.db | cut -c1-220 > profiles/r${R}_kernel_stats_bs1.txt
     python tools/rocprof_summary.py gpurun_out/prof_r${R}/r${R}_results.db | cut -c1-220 > profiles/r${R}_kernel_stats.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_fetch/fetch_results.db dcx_ > profiles/r${R}_pmc_fetch_size.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_write/write_results.db dcx_ > profiles/r${R}_pmc_write_size.txt
