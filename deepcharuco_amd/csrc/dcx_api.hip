@@ -472,9 +472,25 @@ extern "C" size_t dcx_refiner_workspace_bytes(const dcx_refiner* rf, int max_pat
     return ref_layout(max_patches).total;
 }
 
+namespace {
+// n_hint: how many of the max_patches slots are expected to be live (0: unknown).  The launches are sized for the capacity
+// and skip dead patches through d_total on the device; the hint only steers the tile cost model (at bs=1 the capacity is 64
+// slots but ~16 corners fire: tiles chosen for 64 patches run a 4x longer serial chain per workgroup than needed).
+int refiner_run(const dcx_refiner* rf, const float* d_patches, int max_patches, int n_hint, const int32_t* d_total,
+                const int32_t* d_table, void* d_ws, size_t ws_bytes, int32_t* d_corners, float* d_xy, float* d_heat,
+                void* stream);
+}  // namespace
+
 extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches, int max_patches,
                                    const int32_t* d_total, const int32_t* d_table, void* d_ws, size_t ws_bytes,
                                    int32_t* d_corners, float* d_xy, float* d_heat, void* stream) {
+    return refiner_run(rf, d_patches, max_patches, 0, d_total, d_table, d_ws, ws_bytes, d_corners, d_xy, d_heat, stream);
+}
+
+namespace {
+int refiner_run(const dcx_refiner* rf, const float* d_patches, int max_patches, int n_hint, const int32_t* d_total,
+                const int32_t* d_table, void* d_ws, size_t ws_bytes, int32_t* d_corners, float* d_xy, float* d_heat,
+                void* stream) {
     if (!rf || !d_patches || !d_ws) return DCX_E_ARG;
     if (d_xy != nullptr && d_table == nullptr) return DCX_E_ARG;
     if (max_patches <= 0 || max_patches > (1 << 22)) return DCX_E_SHAPE;
@@ -508,6 +524,7 @@ extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches
     for (const Step& st : steps) {
         const DevLayer& l = rf->mid[st.layer];
         DcxConvArgs a = conv_args(l, src, p, l.cin / 4, 0, st.hin, st.hin, st.ups, st.pad, dst, l.cout / 4, lim);
+        a.n_hint = lim != nullptr ? n_hint : 0;
         rc = dcx_launch_conv_mfma(a, 3, st.pool, DCX_EPI_BNRELU, s);
         if (rc) return rc;
         float* t = src; src = dst; dst = t;
@@ -525,6 +542,7 @@ extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches
     return dcx_launch_refine_finalize((const float*)(ws + L.pval), (const int*)(ws + L.pidx), heat_tiles, 64, p, lim,
                                       d_table, d_corners, d_xy, s);
 }
+}  // namespace
 
 // ---- whole pipeline -----------------------------------------------------------------------------
 namespace {
@@ -589,8 +607,9 @@ int infer_range(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d
                                 (float*)(ws + L.patches), stream);
     if (rc) return rc;
     if (timing && (rc = timing_mark(2, s))) return rc;
-    rc = dcx_refiner_forward(rf, (const float*)(ws + L.patches), p, total, table, ws + L.ref, L.total - L.ref, nullptr,
-                             d_xy, nullptr, stream);
+    // expected live patches: a board has n_ids corners, so ~n_ids fire per frame (the capacity kmax is usually larger)
+    rc = refiner_run(rf, (const float*)(ws + L.patches), p, batch * (kmax < det->n_ids ? kmax : det->n_ids), total, table,
+                     ws + L.ref, L.total - L.ref, nullptr, d_xy, nullptr, stream);
     if (rc) return rc;
     return timing ? timing_mark(3, s) : 0;
 }

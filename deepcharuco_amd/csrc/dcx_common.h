@@ -42,6 +42,8 @@ struct DcxConvArgs {
     float* part_val;       // [N][tiles] per-tile maximum
     int* part_idx;         // [N][tiles] flat index (y*Wo+x) of the first maximum in the tile
     int n;
+    int n_hint;            // > 0 with n_limit: the number of images the launch is EXPECTED to process (n is only the capacity);
+                           // used by the tile cost model, never by the kernel
     int in_cq_total, in_cq_off;
     int cin;               // multiple of 32
     int hin, win;          // physical input size
