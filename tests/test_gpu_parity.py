@@ -906,8 +906,9 @@ print("RESULT", n, h.hexdigest())
 
 
 def test_kernel_families_give_identical_corners(dev):
-    """The same 32 frames through the three convolution kernel families -- direct only, 1-D Winograd, 2-D Winograd (the
-    default) -- must give identical corner lists (ids, integer cells, sub-pixel xy): the families differ in fp32 rounding
+    """The same 32 frames through the convolution kernel families -- direct only, 1-D Winograd, 2-D Winograd + phase
+    kernels (the default), the default without the phase kernels and with the flat item walk, deterministic mode -- must
+    give identical corner lists (ids, integer cells, sub-pixel xy): the families differ in fp32 rounding
     (each is bit-exact against ITS restatement), and the arg-max outputs must not notice.  Each family runs in its own
     process because the switches are read once per process."""
     import subprocess
@@ -917,7 +918,9 @@ def test_kernel_families_give_identical_corners(dev):
     delta = float(sd["convDb.bias"][16] - W.synthetic_state_dict("detector", 2024)["convDb.bias"][16])
     script = _FAMILY_SCRIPT.format(repo=REPO, delta=delta)
     results = {}
-    for name, env in (("direct", {"DCX_WINO": "0", "DCX_WINO2": "0"}), ("wino1d", {"DCX_WINO2": "0"}), ("wino2d", {})):
+    for name, env in (("direct", {"DCX_WINO": "0", "DCX_WINO2": "0", "DCX_UPS2": "0"}), ("wino1d", {"DCX_WINO2": "0"}),
+                      ("wino2d", {}), ("no_phase_flat_walk", {"DCX_UPS2": "0", "DCX_XCD_WALK": "0"}),
+                      ("deterministic", {"DCX_DETERMINISTIC": "1"})):
         e = dict(os.environ)
         e.pop("DCX_FORCE_CFG", None)
         e.update(env)
@@ -927,7 +930,31 @@ def test_kernel_families_give_identical_corners(dev):
         results[name] = line[0].split()[1:]
     _report("kernel_families", {k: dict(corners=int(v[0]), sha256=v[1][:16]) for k, v in results.items()})
     assert int(results["wino2d"][0]) > 200
-    assert results["direct"] == results["wino1d"] == results["wino2d"], results
+    assert len({tuple(v) for v in results.values()}) == 1, results
+
+
+def test_bench_script_emits_parity_block_and_exit_code(dev):
+    """bench.py is the driver's measurement: a short run must print ONE JSON line whose parity block is clean (rc 0), with
+    a truthful workload label; and the parity gate must really gate (a corrupted result -> rc 3)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("DCX_FORCE_CFG", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+           "--parity-frames", "3"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["parity"]["frames_checked"] == 3 and d["parity"]["mismatched_frames"] == 0 and d["parity"]["corners"] > 0
+    assert "BASELINE configs[1]" in d["config"]["workload"] and d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma"
+    out = subprocess.run(cmd + ["--batch", "5", "--height", "120", "--width", "160"], env=env, capture_output=True, text=True, timeout=600)
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert out.returncode == 0 and "not a BASELINE config" in d["config"]["workload"]
+    env["DCX_BENCH_CORRUPT_PARITY"] = "1"          # test hook: bench flips one result before the comparison
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 3 and "PARITY FAILURE" in out.stderr
 
 
 def test_pitched_frame_buffer_through_c_abi(dev, golden_tiny):
