@@ -2,6 +2,7 @@
 #include "dcx_conv_mfma.h"
 #include "dcx_conv_wino.h"
 #include "dcx_conv_wino2.h"
+#include "dcx_conv_wino2h.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -44,6 +45,12 @@ struct CfgEntry {
     { 64, 256, TH, TW, 3, POOL, DCX_EPI_BNRELU, 16, 0, 1, 2, 0,                                              \
       &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, (POOL) != 0>>,                                        \
       "dcx_conv_wino2_kernel<DcxWino2Cfg<" #TH "," #TW "," #POOL ">>" }
+
+// 2-D Winograd on half-size tiles (dcx_conv_wino2h.h): 64 couts x 32 2x2-tiles, 128 accumulators, two workgroups per CU
+#define DCX_W2HCFG(TH, TW, POOL)                                                                      \
+    { 64, 128, TH, TW, 3, POOL, DCX_EPI_BNRELU, 8, 0, 1, 3, 0,                                               \
+      &dcx_conv_wino2h_launch_cfg<DcxWino2hCfg<TH, TW, (POOL) != 0>>,                                      \
+      "dcx_conv_wino2h_kernel<DcxWino2hCfg<" #TH "," #TW "," #POOL ">>" }
 
 #define DCX_W2CFG_G(TH, TW, G)                                                                        \
     { 64, 256, TH, TW, 3, 0, DCX_EPI_BNRELU, 16, 0, G, 2, 0,                                                \
@@ -107,7 +114,18 @@ const CfgEntry kCfgs[] = {
     DCX_PCFG(1, 4, 2, 2, 16, 16, DCX_EPI_BNRELU),
     DCX_PCFG(2, 2, 1, 1, 8, 8, DCX_EPI_BNRELU),
     DCX_PCFG(1, 4, 2, 2, 8, 32, DCX_EPI_HEAT),
+    // 2-D Winograd, half-size tiles, two workgroups per CU (cout_pad <= 128: the per-channel constants must leave room for two)
+    DCX_W2HCFG(8, 16, 0),
+    DCX_W2HCFG(8, 16, 1),
+    DCX_W2HCFG(6, 20, 0),     // 3 x 10 tiles: 30x40 and 60x80 maps without padding, RefineNet's 18/20-pixel maps at 83-90 %
+    DCX_W2HCFG(6, 20, 1),
 };
+
+int dcx_wino2h_mode() {   // DCX_WINO2H: 0 = never, 1 = cost model (default), 2 = whenever it can run the layer (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_WINO2H"); v = e ? atoi(e) : 1; }
+    return v;
+}
 
 int dcx_ups2_enabled() {   // on by default; DCX_UPS2=0 keeps up-sampled layers on the Winograd / direct kernels (A/B runs)
     static int v = -1;
@@ -166,7 +184,8 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
     if (force != nullptr && force[0] != 0) {
         for (const CfgEntry& c : kCfgs)
             if (strcmp(c.name, force) == 0 && c.ks == ks && c.pool == pool && c.epi == epi && cout_pad % c.cout_tile == 0 &&
-                (c.group == 1 || (allow_group && ho <= c.th && wo <= c.tw)) && (!c.ups2 || ups == 1))
+                (c.group == 1 || (allow_group && ho <= c.th && wo <= c.tw)) && (!c.ups2 || ups == 1) &&
+                (c.wino != 3 || (cout_pad <= 128 && cin >= 2 * DCX_CCH)))
                 return &c;
     }
     for (const CfgEntry& c : kCfgs) {
@@ -175,6 +194,19 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         if (c.inlane && !dcx_inlane_pool_enabled()) continue;
         if (c.wino == 1 && (!dcx_wino_enabled() || dcx_deterministic_enabled())) continue;
         if (c.wino == 2 && (!dcx_wino2_enabled() || dcx_deterministic_enabled())) continue;
+        if (c.wino == 3) {   // half-tile 2-D Winograd: two co-resident workgroups share a CU's matrix pipes
+            if (!dcx_wino2_enabled() || dcx_deterministic_enabled() || dcx_wino2h_mode() == 0 || cout_pad > 128 || cin < 2 * DCX_CCH) continue;
+            const long ht = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
+            const double items_h = (double)n * (cout_pad / c.cout_tile) * ht;
+            const int units_h = cin / DCX_CCH;
+            // per item: 64 MFMA-equivalents per unit at 64 cycles + the transform's serial VALU + half an epilogue; stalls are
+            // hidden by the co-resident workgroup (measured factor, tools/unit_probe.py)
+            const double item_cost_h = (double)units_h * (64 * 64.0 + 560.0) + 2600.0;
+            double cost_h = (double)(((long)items_h + n_cu - 1) / n_cu) * item_cost_h;
+            if (dcx_wino2h_mode() == 2) cost_h = 1.0;
+            if (best == nullptr || cost_h < best_cost) { best_cost = cost_h; best = &c; }
+            continue;
+        }
         if (c.group > 1 && (!allow_group || ho > c.th || wo > c.tw)) continue;   // grouped tiles: whole small maps only
         if (c.ups2) {      // phase variant: only for layers reading a x2 up-sampled input; tiles are low-resolution, x4 items,
                            // 8 k-steps (4 taps x 2) per 16-channel unit

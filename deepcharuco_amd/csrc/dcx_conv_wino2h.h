@@ -1,0 +1,451 @@
+// dcx_conv_wino2h.h -- the 2-D Winograd F(2x2, 3x3) convolution of dcx_conv_wino2.h on HALF-SIZE tiles with
+// v_mfma_f32_16x16x4_f32, so that a wave holds 128 accumulator registers instead of 256 and TWO workgroups share a CU.
+//
+// Why: an fp32 MFMA owns the vector ALU and a co-resident wave only ever runs while the other one stalls (DESIGN.md 3.8,
+// tools/ubench/mfma_overlap.hip).  dcx_conv_wino2.h needs the whole 512-register file for one wave per SIMD, so every wait
+// of that wave (two barriers per unit, LDS / L2 latencies of the transform and the operands, scalar bookkeeping between
+// units, the store tail of the epilogue) idles the matrix pipe: ~13 % of a work item.  Here the second workgroup fills them.
+//
+//   workgroup = 4 waves = 64 couts x 32 2x2-tiles (8x16 output pixels); wave wm owns couts 16 wm .. 16 wm + 15 for ALL 32
+//   tiles (two 16-tile MFMA blocks) and all 16 Winograd positions: 16 x 2 x 4 = 128 accumulator registers (AGPRs).
+//   v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) B(4x16); lane l supplies A[l % 16][l / 16], B[l / 16][l % 16] and holds
+//   D[4 (l / 16) + r][l % 16], r = 0..3.  With the C4 layouts a lane's float4 is channels 4g .. 4g+3 (g = l / 16) of its
+//   cout (A: weights [pos][cin/4][cout_pad][4]) or of its tile (B: sV[pos][cq][tile]); MFMA j consumes component j, i.e.
+//   channels {j, 4+j, 8+j, 12+j} of the 16-channel chunk.  One float4 per operand covers the whole chunk.
+//   Summation order of every m (restated bit-exactly by oracle/conv_exact.c, dcx_oracle_conv_wino2_exact(order = 1)):
+//       m = 0;  for chunk c (16 cin) / j in 0..3 / g in 0..3:  m = fmaf(u[16c + 4g + j], v[16c + 4g + j], m)
+//   Input transform, host-side weight transform, output transform (sixteen chained v_mfma_f32_4x4x1 per accumulator
+//   register), BN, ReLU, pooling: exactly dcx_conv_wino2.h.
+//
+// Per unit (16 channels) a wave issues 16 positions x 8 MFMAs x 32 cycles = 4,096 matrix cycles; operands: one weight float4
+// (L2) and two activation float4 (LDS) per position.  Weight traffic per CU equals the big-tile kernel's (a wave covers all 32
+// tiles of its workgroup); LDS operand traffic doubles to ~32 B/clk/CU, well inside the 128 B/clk.  Staging = the big kernel's
+// scheme on a [4 cq][10][18] raw tile: 3 raw float4 per thread, mid barrier, then each thread transforms HALF a (cq, tile)
+// piece (two of the four xi rows: 12 ds_read_b128, 32 v_pk_add_f32, 8 ds_write_b128).  LDS 76 KB + per-channel constants.
+#pragma once
+#include "dcx_conv_wino2.h"
+
+template <int TH_, int TW_, bool POOL_, int EPI_ = DCX_EPI_BNRELU>
+struct DcxWino2hCfg {
+    static constexpr int TH = TH_, TW = TW_;
+    static constexpr bool POOL = POOL_;
+    static constexpr int EPI = EPI_;
+    static constexpr int NTHREADS = 256;
+    static constexpr int COUT_TILE = 64;
+    static constexpr int TY = TH / 2, TX = TW / 2;
+    static constexpr int NTILES = TY * TX;                 // <= 32
+    static constexpr int HH = TH + 2, RW = TW + 2;
+    static constexpr int CQC = DCX_CCH / 4;
+    static constexpr int RAW = CQC * HH * RW;
+    static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;
+    static constexpr int RAW_PAD = ITER_R * NTHREADS;
+    static constexpr int VPLANE = CQC * 32;                // float4 per position: [cq][tile]
+    static constexpr int LDS_FLOAT4 = 16 * VPLANE;         // one transformed buffer (32 KB)
+    static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_PAD) * 16;
+    static constexpr int DQ = 5;                           // weights: positions ahead
+    static constexpr int DQB = 2;                          // transformed activations: positions ahead
+    // staging schedule in events (two per position: 32 per unit, 128 matrix cycles apart)
+    static constexpr int E_RAW_LOAD = 0;
+    static constexpr int E_RAW_STORE = 9;
+    static constexpr int E_XFORM = 14;                     // mid barrier before this event; 12 transform events follow
+    static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 32 && NTILES > 16, "tile must hold 17..32 2x2 tiles");
+    static_assert(ITER_R <= 5 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM + 12 <= 32, "staging does not fit the schedule");
+    static_assert(EPI == DCX_EPI_BNRELU, "plain BN + ReLU (+ pool) layers only");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 sB[];
+    constexpr int TX = C::TX, RW = C::RW, ITER_R = C::ITER_R, LDSF = C::LDS_FLOAT4, CQC = C::CQC, VPLANE = C::VPLANE;
+    constexpr int DQ = C::DQ, DQB = C::DQB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = 16-cout group
+    const int g4 = lane >> 4, l15 = lane & 15;                      // lane's channel quad of the chunk / row-or-column
+
+    // ---- work list (persistent, XCD-aware walk: see dcx_conv_wino2.h) ------------------------------------------
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int n_ct = a.cout_pad / C::COUT_TILE;
+    int n_eff = a.n;
+    if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
+    const int total = n_eff * n_ct * tiles;
+    int w = blockIdx.x, w_end = total, gstride = gridDim.x;
+    if (a.xcd_walk && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7;
+        const int lo = (int)(((long)total * x) >> 3);
+        w_end = (int)(((long)total * (x + 1)) >> 3);
+        gstride = gridDim.x >> 3;
+        w = lo + (blockIdx.x >> 3);
+    }
+    if (w >= w_end) return;
+    if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+        a.clk_probe[0] = __builtin_amdgcn_s_memtime();
+        a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    const int nch = a.cin / DCX_CCH;
+    auto decode = [&](int wi) {
+        DcxItem it;
+        it.tx = wi % a.tiles_x; wi /= a.tiles_x;
+        it.ty = wi % a.tiles_y; wi /= a.tiles_y;
+        it.ct = wi % n_ct;
+        it.n = wi / n_ct;
+        it.ph = 0;
+        return it;
+    };
+    const int hl = a.hin << a.ups, wl = a.win << a.ups;
+
+    // ---- operand fetch -----------------------------------------------------------------------------------------
+    // weights [pos][cin/4][cout_pad][4]: lane (r = l15, g = g4) reads cout wm*16 + r, channel quad g of the chunk
+    const unsigned w_lane_off = (unsigned)(g4 * a.cout_pad + wm * 16 + l15) * 16u;
+    const unsigned w_pos_stride = (unsigned)((a.cin >> 2) * a.cout_pad) * 16u;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w_wino2), (short)0, (int)(16u * w_pos_stride), 0x00020000);
+    auto unit_wbase = [&](const DcxItem& it, int c) {
+        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u;
+    };
+    auto load_a = [&](unsigned wbase, int pos) {
+        const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane_off, wbase + (unsigned)pos * w_pos_stride, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    // transformed activations sV[buf][pos][cq][tile]: lane (n = l15, g = g4) reads tile tb*16 + n, channel quad g
+    const int tile_b = g4 * 32 + l15;
+    auto load_b = [&](int buf, int pos, int tb) { return sB[buf * LDSF + pos * VPLANE + tile_b + tb * 16]; };
+
+    // ---- staging: raw tile ---------------------------------------------------------------------------------------
+    int r_hy[ITER_R], r_hx[ITER_R];
+    unsigned r_rel[ITER_R];
+#pragma unroll
+    for (int k = 0; k < ITER_R; ++k) {
+        const int idx = tid + k * C::NTHREADS;
+        const int cq = idx / (C::HH * RW);
+        const int hp = idx - cq * (C::HH * RW);
+        r_hy[k] = hp / RW;
+        r_hx[k] = hp - r_hy[k] * RW;
+        const int prow = ((r_hy[k] - a.pad) >> a.ups) + a.pad, pcol = ((r_hx[k] - a.pad) >> a.ups) + a.pad;
+        r_rel[k] = idx < C::RAW ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
+    }
+    float4* sR = sB + 2 * LDSF;
+    // transform piece of this thread: half h (xi rows 2h, 2h + 1) of (cq, tile); tiles past the end redo the last tile
+    const int x_h = __builtin_amdgcn_readfirstlane(tid >> 7);          // wave-uniform: waves 0, 1 -> xi 0, 1; waves 2, 3 -> xi 2, 3
+    const int x_cq = (tid >> 5) & 3;
+    const int x_tile = min(tid & 31, C::NTILES - 1);
+    const int x_ty = x_tile / TX, x_tx = x_tile - x_ty * TX;
+    const int x_src = (x_cq * C::HH + 2 * x_ty) * RW + 2 * x_tx;       // raw index of the window's top-left pixel
+    // rows of the half-piece, branch-free: first xi = row A - row B, second xi = row B + sgn * row C
+    //   h = 0: xi 0 = d0 - d2 (A = 0, B = 2), xi 1 = d1 + d2 (C = 1, sgn = +1);  h = 1: xi 2 = d2 - d1 (A = 2, B = 1), xi 3 = d1 - d3 (C = 3, sgn = -1)
+    const int x_ra = x_src + (x_h ? 2 : 0) * RW, x_rb = x_src + (x_h ? 1 : 2) * RW, x_rc = x_src + (x_h ? 3 : 1) * RW;
+    const float x_sg = x_h ? -1.f : 1.f;
+    const dcx_f32x2 x_sgn = {x_sg, x_sg};
+    const int x_dst = (8 * x_h) * VPLANE + x_cq * 32 + x_tile;         // + local position * VPLANE
+    auto unit_rsrc = [&](const DcxItem& it, int c) {
+        const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
+        const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
+                                    + tile_off) * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
+    };
+    auto tile_interior = [&](const DcxItem& it) {
+        const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
+        return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + RW <= wl;
+    };
+    auto stage_fetch = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        const dcx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto sub4 = [](const float4& x, const float4& y) {
+        const dcx_f32x2 lo = dcx_pk_sub(dcx_f32x2{x.x, x.y}, dcx_f32x2{y.x, y.y}), hi = dcx_pk_sub(dcx_f32x2{x.z, x.w}, dcx_f32x2{y.z, y.w});
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto add4 = [](const float4& x, const float4& y) {
+        const dcx_f32x2 lo = dcx_pk_add(dcx_f32x2{x.x, x.y}, dcx_f32x2{y.x, y.y}), hi = dcx_pk_add(dcx_f32x2{x.z, x.w}, dcx_f32x2{y.z, y.w});
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    };
+    // Half-piece transform as 12 events (x = 0..11).  Rows needed: h = 0: xi 0 = d0 - d2, xi 1 = d1 + d2;  h = 1: xi 2 = d2 - d1, xi 3 = d1 - d3.
+    //   event 0: read the two rows of the first xi (8 ds_read_b128)      event 1: read the third row
+    //   event 3 + ms (ms = 0..7, local position = 4 * (xi - 2h) + nu): at nu == 0 form t (4 float4 ops), then the position
+    //   (1 float4 op); its LDS write goes out one event later           event 11: last write
+    float4 xa[4], xb[4], xc[4], xt[4], xv;
+    auto fma4s = [&](const float4& x, const float4& y) {      // y + sgn * x as two v_pk_fma_f32 (sgn = +-1: exactly y +- x)
+        const dcx_f32x2 lo = __builtin_elementwise_fma(dcx_f32x2{x.x, x.y}, x_sgn, dcx_f32x2{y.x, y.y});
+        const dcx_f32x2 hi = __builtin_elementwise_fma(dcx_f32x2{x.z, x.w}, x_sgn, dcx_f32x2{y.z, y.w});
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto xform_event = [&](float4* vbuf, int x) {
+        if (x == 0) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) { xa[cidx] = sR[x_ra + cidx]; xb[cidx] = sR[x_rb + cidx]; }
+        } else if (x == 1) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) xc[cidx] = sR[x_rc + cidx];
+        } else if (x >= 3) {
+            const int ms = x - 3;
+            if (ms > 0) vbuf[x_dst + (ms - 1) * VPLANE] = xv;
+            if (ms < 8) {
+                const int xl = ms >> 2, nu = ms & 3;
+                if (nu == 0) {
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx) xt[cidx] = xl == 0 ? sub4(xa[cidx], xb[cidx]) : fma4s(xc[cidx], xb[cidx]);
+                }
+                xv = nu == 0 ? sub4(xt[0], xt[2]) : nu == 1 ? add4(xt[1], xt[2]) : nu == 2 ? sub4(xt[2], xt[1]) : sub4(xt[1], xt[3]);
+            }
+        }
+    };
+
+    // ---- epilogue constants in LDS: alpha, beta2, output-transform table -----------------------------------------
+    float4* sP = sB + 2 * LDSF + C::RAW_PAD;
+    const int cq_pad = a.cout_pad >> 2;
+    for (int i = tid; i < cq_pad; i += C::NTHREADS) {
+        sP[i] = reinterpret_cast<const float4*>(a.alpha)[i];
+        sP[cq_pad + i] = reinterpret_cast<const float4*>(a.beta)[i];
+    }
+    float* sT = reinterpret_cast<float*>(sP + 2 * cq_pad);
+    if (tid < 64) {
+        const int k = tid >> 4, p = tid & 15, i = k >> 1, j = k & 1, xi = p >> 2, nu = p & 3;
+        const int ci = i == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : xi == 1 ? 1 : -1);
+        const int cj = j == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : nu == 1 ? 1 : -1);
+        sT[tid] = (float)(ci * cj);
+    }
+    const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
+
+    // accumulators: acc[pos][tb], only ever defined by inline asm with an AGPR constraint (see dcx_conv_wino2.h)
+    dcx_f32x4 acc[16][2];
+
+    // ---- prologue: first unit staged synchronously ---------------------------------------------------------------
+    DcxItem cur = decode(w);
+    int c = 0;
+    float4 a_c[DQ];
+    {
+        const unsigned wb = unit_wbase(cur, 0);
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) a_c[d] = load_a(wb, d);
+        const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(cur, 0);
+        const int sy0 = cur.ty * C::TH - a.pad, sx0 = cur.tx * C::TW - a.pad;
+#pragma unroll
+        for (int k = 0; k < ITER_R; ++k) {
+            const int ly = sy0 + r_hy[k], lx = sx0 + r_hx[k];
+            const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+            sR[tid + k * C::NTHREADS] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 12; ++x) xform_event(sB, x);
+    }
+
+#ifdef DCX_W2H_DEBUG_DUMP
+    __syncthreads();
+    for (int i = tid; i < LDSF; i += C::NTHREADS) reinterpret_cast<float4*>(a.out)[i] = sB[i];     // transformed tile of unit 0
+    return;
+#endif
+    int u = 0;
+    auto run_unit = [&](auto zero_t) -> bool {
+        constexpr bool ZERO = decltype(zero_t)::value;
+        DcxItem nxt = cur;
+        int cn = c + 1;
+        bool has_next = true;
+        if (cn == nch) {
+            if (w + gstride < w_end) { nxt = decode(w + gstride); cn = 0; }
+            else { has_next = false; cn = c; }
+        }
+        const int buf = u & 1;
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[4 + 3 * u] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[5 + 3 * u] = __builtin_amdgcn_s_memtime();
+
+        const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
+        const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
+        const unsigned wb_cur = unit_wbase(cur, c);
+        const unsigned wb_nxt = unit_wbase(nxt, cn);
+        float4 aq[16 + DQ], bq[16][2];
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) aq[d] = a_c[d];
+#pragma unroll
+        for (int d = 0; d < DQB; ++d) { bq[d][0] = load_b(buf, d, 0); bq[d][1] = load_b(buf, d, 1); }
+        float4* vnext = sB + (buf ^ 1) * LDSF;
+        float4 rv[ITER_R];
+        const bool n_interior = tile_interior(nxt);
+        unsigned roff[ITER_R];
+#pragma unroll
+        for (int k = 0; k < ITER_R; ++k) roff[k] = r_rel[k];
+        if (!n_interior) {
+#pragma unroll
+            for (int k = 0; k < ITER_R; ++k) {
+                const int ly = nsy0 + r_hy[k], lx = nsx0 + r_hx[k];
+                const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+                roff[k] = inb ? r_rel[k] : 0x80000000u;
+            }
+        }
+        // one position = 8 MFMAs (tb 0 / 1 alternating, j = 0..3) in two slots of four; each slot is preceded by one
+        // staging event; slot 0 also fetches the operands of position p + DQ / p + DQB
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            if (p * 2 == C::E_XFORM) __syncthreads();       // the raw tile of the next unit is complete in sR
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (slot == 0) {
+                    const int q = p + DQ, qb2 = p + DQB;
+                    if (q < 16) aq[q] = load_a(wb_cur, q);
+                    else aq[q] = load_a(wb_nxt, q - 16);
+                    if (qb2 < 16) { bq[qb2][0] = load_b(buf, qb2, 0); bq[qb2][1] = load_b(buf, qb2, 1); }
+                }
+                {
+                    const int e = p * 2 + slot;          // staging event 0 .. 31
+                    if (e >= C::E_RAW_LOAD && e < C::E_RAW_LOAD + ITER_R) rv[e - C::E_RAW_LOAD] = stage_fetch(rs_n, roff[e - C::E_RAW_LOAD]);
+                    if (e >= C::E_RAW_STORE && e < C::E_RAW_STORE + ITER_R) sR[tid + (e - C::E_RAW_STORE) * C::NTHREADS] = rv[e - C::E_RAW_STORE];
+                    if (e >= C::E_XFORM && e < C::E_XFORM + 12) xform_event(vnext, e - C::E_XFORM);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const float4 aa = aq[p], b0 = bq[p][0], b1 = bq[p][1];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = 2 * slot + jj;
+                        const float av = j == 0 ? aa.x : j == 1 ? aa.y : j == 2 ? aa.z : aa.w;
+                        const float bv0 = j == 0 ? b0.x : j == 1 ? b0.y : j == 2 ? b0.z : b0.w;
+                        const float bv1 = j == 0 ? b1.x : j == 1 ? b1.y : j == 2 ? b1.z : b1.w;
+                        // (hazards: see dcx_conv_wino2.h -- operands come from loads hipcc waits for; VALU-written candidates only
+                        //  at the very start of a unit -> 2 wait states ahead of the first MFMA)
+                        if (p == 0 && j == 0) asm volatile("s_nop 1");
+                        if (ZERO && j == 0) {       // first touch of these two accumulators in this work item: C = 0
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[p][0]) : "v"(av), "v"(bv0));
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[p][1]) : "v"(av), "v"(bv1));
+                        } else {
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][0]) : "v"(av), "v"(bv0));
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][1]) : "v"(av), "v"(bv1));
+                        }
+                    }
+#ifdef DCX_W2H_DEBUG_NOP
+                    asm volatile("s_nop 7\n\ts_nop 7");
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) a_c[d] = aq[16 + d];
+
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[6 + 3 * u] = __builtin_amdgcn_s_memtime();
+        if (c == nch - 1 && (!ZERO || nch == 1)) {
+            // ---- epilogue: output transform on the matrix cores, BN, ReLU (, pool), store -----------------------------
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // 8-pass MFMA result -> read as srcB: make the distance explicit
+#pragma unroll
+            for (int p = 0; p < 16; ++p) { asm volatile("" : "+a"(acc[p][0])); asm volatile("" : "+a"(acc[p][1])); }
+            const unsigned plane = (unsigned)(hs * ws);
+            const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 4 + g4;          // the lane's output channel quad
+            char* obase = reinterpret_cast<char*>(a.out)
+                        + ((size_t)cur.n * a.out_cq_total + a.out_cq_off + cq) * (size_t)plane * 16;
+            float cf[16];
+            {
+                const float4* tp = reinterpret_cast<const float4*>(sT + (lane & 3) * 16);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 t4 = tp[q4];
+                    cf[4 * q4] = t4.x; cf[4 * q4 + 1] = t4.y; cf[4 * q4 + 2] = t4.z; cf[4 * q4 + 3] = t4.w;
+                }
+            }
+            dcx_f32x4 e[2][4];        // e[tb][i][k]: output k of cout 4 * cq + i for the lane's tile tb * 16 + l15
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (p == 0) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=v"(e[tb][i]) : "v"(cf[0]), "a"(acc[0][tb][i]));
+                        else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(e[tb][i]) : "v"(cf[p]), "a"(acc[p][tb][i]));
+                    }
+                }
+            }
+            asm volatile("s_nop 7" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]),
+                                     "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[1][2]), "+v"(e[1][3]));
+            const float4 al = sP[cq], be = sP[cq_pad + cq];
+            const dcx_f32x2 al01 = {al.x, al.y}, al23 = {al.z, al.w}, be01 = {be.x, be.y}, be23 = {be.z, be.w};
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int qt = tb * 16 + l15;
+                const int qty = qt / TX, qtx = qt - qty * TX;
+                const int oy0 = cur.ty * C::TH + 2 * qty, ox0 = cur.tx * C::TW + 2 * qtx;
+                const bool qok = qt < C::NTILES && cq < a.cout_quads;
+                const bool okr0 = qok && oy0 < a.ho, okr1 = qok && oy0 + 1 < a.ho;
+                const bool okc0 = ox0 < a.wo, okc1 = ox0 + 1 < a.wo;
+                dcx_f32x2 bn[4][2];     // [i][k / 2]
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kp = 0; kp < 2; ++kp) {
+                        const dcx_f32x2 x = {e[tb][i][2 * kp], e[tb][i][2 * kp + 1]};
+                        const dcx_f32x2 aa = i < 2 ? al01 : al23, bb = i < 2 ? be01 : be23;
+                        if ((i & 1) == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(bn[i][kp]) : "v"(x), "v"(aa), "v"(bb));
+                        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(bn[i][kp]) : "v"(x), "v"(aa), "v"(bb));
+                    }
+                float4 y[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    y[k] = make_float4(bn[0][k >> 1][k & 1], bn[1][k >> 1][k & 1], bn[2][k >> 1][k & 1], bn[3][k >> 1][k & 1]);
+                if (C::POOL) {
+                    float4 v;
+                    v.x = dcx_vmax(dcx_vmax(dcx_vmax(y[0].x, y[1].x), dcx_vmax(y[2].x, y[3].x)), 0.f);
+                    v.y = dcx_vmax(dcx_vmax(dcx_vmax(y[0].y, y[1].y), dcx_vmax(y[2].y, y[3].y)), 0.f);
+                    v.z = dcx_vmax(dcx_vmax(dcx_vmax(y[0].z, y[1].z), dcx_vmax(y[2].z, y[3].z)), 0.f);
+                    v.w = dcx_vmax(dcx_vmax(dcx_vmax(y[0].w, y[1].w), dcx_vmax(y[2].w, y[3].w)), 0.f);
+                    char* dst = obase + (size_t)((unsigned)((oy0 >> 1) * ws + (ox0 >> 1)) * 16u);
+                    if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        y[k].x = dcx_vmax(y[k].x, 0.f); y[k].y = dcx_vmax(y[k].y, 0.f);
+                        y[k].z = dcx_vmax(y[k].z, 0.f); y[k].w = dcx_vmax(y[k].w, 0.f);
+                    }
+                    char* dst = obase + (size_t)((unsigned)(oy0 * ws + ox0) * 16u);
+                    if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = y[0];
+                    if (okr0 && okc1) *reinterpret_cast<float4*>(dst + 16) = y[1];
+                    if (okr1 && okc0) *reinterpret_cast<float4*>(dst + (size_t)ws * 16) = y[2];
+                    if (okr1 && okc1) *reinterpret_cast<float4*>(dst + (size_t)ws * 16 + 16) = y[3];
+                }
+            }
+        }
+
+        if (!has_next) {
+            if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
+                a.clk_probe[2] = __builtin_amdgcn_s_memtime();
+                a.clk_probe[3] = __builtin_amdgcn_s_memrealtime();
+            }
+            return false;
+        }
+        if (cn == 0) w += gstride;
+        cur = nxt;
+        c = cn;
+        ++u;
+        return true;
+    };
+    // work items: first unit (C = 0), then the remaining nch - 1 units (the last one runs the epilogue); nch >= 2
+    for (;;) {
+        run_unit(std::true_type{});
+        bool more = true;
+        while (c != 0 && more) more = run_unit(std::false_type{});
+        if (!more) break;
+    }
+}
+
+template <class C>
+static int dcx_conv_wino2h_launch_cfg(DcxConvArgs a, hipStream_t stream) {
+    a.tiles_x = (a.wo + C::TW - 1) / C::TW;
+    a.tiles_y = (a.ho + C::TH - 1) / C::TH;
+    if (a.w_wino2 == nullptr || a.alpha == nullptr || a.beta == nullptr || a.out == nullptr) return DCX_E_ARG;
+    if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0 || a.cin < 2 * DCX_CCH) return DCX_E_SHAPE;   // >= 2 units per work item
+    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
+    if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
+    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 8 + 256;      // + alpha, beta2, output-transform table
+    if (2 * lds > 160 * 1024) return DCX_E_SHAPE;                        // the point of this kernel is two workgroups per CU
+    const long resident = 2L * dcx_device_cu_count();
+    const long blocks = items < resident ? items : resident;
+    a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
+    static bool attr_set[DCX_MAX_DEVICES] = {};
+    const int dev_i = dcx_current_device();
+    if (!attr_set[dev_i]) {
+        DCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcx_conv_wino2h_kernel<C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set[dev_i] = true;
+    }
+    hipLaunchKernelGGL((dcx_conv_wino2h_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), lds, stream, a);
+    return (int)hipGetLastError();
+}

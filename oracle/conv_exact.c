@@ -123,8 +123,10 @@ void dcx_oracle_conv_wino_exact(const float* x, int n, int cin, int h, int w, co
  *   y[i][j] = 0; for p = 4 xi + nu ascending: y[i][j] = fmaf(AT[i][xi]*AT[j][nu], m[xi][nu], y[i][j]), AT = [[1,1,1,0],[0,1,-1,-1]]
  *             (the kernel runs this chain on the matrix cores, v_mfma_f32_4x4x1: all 16 terms, zero coefficients included)
  *   out = max(fmaf(y, alpha, fmaf(bias, alpha, beta)), 0) */
-void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
-                                 const float* alpha, const float* beta, int cout, int pad, float* y) {
+/* order 0: dcx_conv_wino2.h (v_mfma_f32_32x32x2: chunk / s / j / k, ci = c0 + 8s + 4k + j);
+ * order 1: dcx_conv_wino2h.h (v_mfma_f32_16x16x4: chunk / j / g, ci = c0 + 4g + j) */
+static void conv_wino2_impl(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                            const float* alpha, const float* beta, int cout, int pad, float* y, int order) {
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
     const int nty = (ho + 1) / 2, ntx = (wo + 1) / 2;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -134,10 +136,10 @@ void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, c
                 for (int tx = 0; tx < ntx; ++tx) {
                     float m[4][4] = {{0.0f}};
                     for (int c0 = 0; c0 < cin; c0 += 16)
-                        for (int s = 0; s < 2; ++s)
-                            for (int j = 0; j < 4; ++j)
-                                for (int k = 0; k < 2; ++k) {
-                                    const int ci = c0 + 8 * s + 4 * k + j;
+                        for (int step = 0; step < 16; ++step) {
+                                    /* order 0: step = 8s + 2j + k -> ci = c0 + 8s + 4k + j;  order 1: step = 4j + g -> ci = c0 + 4g + j */
+                                    const int ci = order == 0 ? c0 + 8 * (step >> 3) + 4 * (step & 1) + ((step >> 1) & 3)
+                                                              : c0 + 4 * (step & 3) + (step >> 2);
                                     float d[4][4], t[4][4], v[4][4], hh[4][3], u[4][4];
                                     for (int r = 0; r < 4; ++r)
                                         for (int c = 0; c < 4; ++c) {
@@ -186,6 +188,18 @@ void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, c
                                 y[(((size_t)b * cout + co) * ho + oy) * wo + ox] = fmaxf(fmaf(o[i][jj], alpha[co], b2), 0.0f);
                         }
                 }
+}
+
+void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                                 const float* alpha, const float* beta, int cout, int pad, float* y) {
+    conv_wino2_impl(x, n, cin, h, w, wt, bias, alpha, beta, cout, pad, y, 0);
+}
+
+/* the same layer through dcx_conv_wino2h.h (half-size tiles, v_mfma_f32_16x16x4_f32): only the channel order inside a
+ * 16-channel chunk differs */
+void dcx_oracle_conv_wino2h_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                                  const float* alpha, const float* beta, int cout, int pad, float* y) {
+    conv_wino2_impl(x, n, cin, h, w, wt, bias, alpha, beta, cout, pad, y, 1);
 }
 
 /* 3x3 (pad 1) + BN + ReLU over a nearest-x2 UP-SAMPLED input through the phase variant of the direct kernel

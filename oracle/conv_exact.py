@@ -27,7 +27,7 @@ def lib():
 def conv_exact(x, wt, bias, bn=None, pad=1, ups=False, pool=False, wino=False):
     """x NCHW float32; bn = (gamma, beta, mean, var) or None (raw).  Returns NCHW float32.
     wino=True: the summation order of the 1-D Winograd F(2,3) kernel, wino=2: of the 2-D F(2x2,3x3) kernel
-    (3x3 + BN layers only); wino=3: the phase variant of the direct kernel (3x3 pad 1 + BN over an up-sampled input)."""
+    (3x3 + BN layers only), wino=4: of its half-tile variant (dcx_conv_wino2h.h); wino=3: the phase variant of the direct kernel (3x3 pad 1 + BN over an up-sampled input)."""
     x = np.ascontiguousarray(x, np.float32)
     if wino == 3:
         assert ups and bn is not None and pad == 1 and not pool
@@ -59,7 +59,8 @@ def conv_exact(x, wt, bias, bn=None, pad=1, ups=False, pool=False, wino=False):
         lib().dcx_oracle_fold_bn(p(g), p(be), p(mu), p(var), cout, p(alpha), p(beta))
     if wino:     # True / 1: 1-D F(2,3) along x;  2: 2-D F(2x2,3x3)
         assert bn is not None and ks == 3 and cin % 16 == 0
-        fn = lib().dcx_oracle_conv_wino2_exact if wino == 2 else lib().dcx_oracle_conv_wino_exact
+        fn = (lib().dcx_oracle_conv_wino2_exact if wino == 2 else lib().dcx_oracle_conv_wino2h_exact if wino == 4
+              else lib().dcx_oracle_conv_wino_exact)
         fn(p(x), n, cin, h, w, p(wt), p(bias), p(alpha), p(beta), cout, pad, p(y))
     else:
         lib().dcx_oracle_conv_exact(p(x), n, cin, h, w, p(wt), p(bias), p(alpha) if bn is not None else None,
