@@ -208,22 +208,28 @@ def test_shard_range_partition():
 
 
 def test_tile_cost_model_choices():
-    """The host-side tile selection (csrc/dcx_conv_mfma.hip: pick) is a cost model; these are the choices the
-    design relies on: the 2-D Winograd kernel (one workgroup per CU) when a launch has plenty of work (incl. the fused
-    RefineNet head), the 1-D Winograd kernel for medium launches, the 64x64 S tile of the direct kernel when a launch has
-    few items, the direct kernel for 1x1."""
+    """The host-side tile selection (csrc/dcx_conv_mfma.hip: pick) is a cost model; these are the choices the design
+    relies on: the half-tile 2-D Winograd kernel (two workgroups per CU) for the 64/128-cout 3x3 layers, the big-tile 2-D
+    Winograd kernel where the half-tile one cannot run (512 couts: the per-channel constants of two workgroups do not fit
+    the LDS), the phase variant for layers behind an up-sampling, the direct kernel for 1x1 and in deterministic mode."""
     from deepcharuco_amd import _lib
     L = _lib.lib()
     name = lambda *a: L.dcx_conv_pick_name(*a).decode()
-    assert name(32, 64, 240, 320, 64, 3, 1, 0) == "dcx_conv_wino2_kernel<DcxWino2Cfg<16,16,1>>"      # conv1b, bs=32: 2-D Winograd
-    assert name(128, 64, 480, 640, 64, 3, 1, 0) == "dcx_conv_wino2_kernel<DcxWino2Cfg<16,16,1>>"     # conv1b, cfg3
-    assert "DcxWino2Cfg<16,16,0>" in name(32, 64, 120, 160, 64, 3, 0, 0)                 # conv2a
-    assert "DcxWino2Cfg<6,40,0>" in name(32, 128, 30, 40, 512, 3, 0, 0)                  # fused heads' 3x3 on the 30x40 map
-    assert "<2,2,1,1,8,8,3,0,DCX_EPI_BNRELU>" in name(1, 128, 30, 40, 128, 3, 0, 0)      # bs=1: few items -> S tile (direct)
-    assert "DcxWinoCfg<2,2,4,32,1>" in name(1, 64, 240, 320, 64, 3, 1, 0)                # conv1b bs=1: 1-D Winograd (2 workgroups/CU)
-    assert "DcxWino2Cfg<16,16,0,DCX_EPI_HEAT>" in name(512, 64, 64, 64, 64, 3, 0, 2)     # RefineNet head: 2-D Winograd
-    assert "DCX_EPI_HEAT" in name(512, 64, 64, 64, 64, 3, 0, 2)
+    name_ups = lambda *a: L.dcx_conv_pick_name_ups(*a).decode()
+    assert name(32, 64, 240, 320, 64, 3, 1, 0) == "dcx_conv_wino2h_kernel<DcxWino2hCfg<8,16,1>>"     # conv1b, bs=32
+    assert name(128, 64, 480, 640, 64, 3, 1, 0) == "dcx_conv_wino2h_kernel<DcxWino2hCfg<8,16,1>>"    # conv1b, cfg3
+    assert "DcxWino2hCfg<8,16,0>" in name(32, 64, 120, 160, 64, 3, 0, 0)                 # conv2a
+    assert "DcxWino2hCfg<6,20,0>" in name(512, 64, 18, 18, 128, 3, 0, 0)                 # RefineNet conv2a: 18x18 map in 3 tiles of 6x20
+    assert "DcxWino2Cfg<6,40,0>" in name(32, 128, 30, 40, 512, 3, 0, 0)                  # fused heads' 3x3 (512 couts): big tiles
+    assert "DCX_EPI_HEAT,PH>>" in name_ups(512, 64, 64, 64, 64, 3, 0, 2, 1)              # RefineNet head behind the x2 up-sampling
+    assert ",PH>>" in name_ups(512, 128, 32, 32, 64, 3, 0, 0, 1)                         # conv5a
+    assert "DcxWino2Cfg<16,16,0,DCX_EPI_HEAT>" in name(512, 64, 64, 64, 64, 3, 0, 2)     # the same head without the phase variant
     assert "<1,4,2,2,1,256,1,0,DCX_EPI_RAW>" in name(32, 256, 1, 1200, 65, 1, 0, 1)
+    L.dcx_set_deterministic(1)
+    try:
+        assert "dcx_conv_mfma_kernel" in name(32, 64, 240, 320, 64, 3, 1, 0) and ",PH>>" not in name_ups(512, 128, 32, 32, 64, 3, 0, 0, 1)
+    finally:
+        L.dcx_set_deterministic(0)
     assert name(32, 64, 30, 40, 64, 3, 0, 1) == ""                              # no raw 3x3 instantiation
 
 
