@@ -39,9 +39,17 @@ struct DcxWino2hCfg {
     static constexpr int RAW = CQC * HH * RW;
     static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;
     static constexpr int RAW_PAD = ITER_R * NTHREADS;
+    // raw tile in LDS: row pitch RP, row hy shifted by ROWOFF(hy).  The transform reads float4 (row 2 ty + i, col 2 tx + j) for
+    // 16-lane groups that mix four ty: with pitch RW all of them land on the even 16-B slots of the 256-B bank row (4-way
+    // conflicts, 35 % of the kernel's LDS cycles).  For TW = 16 a pitch of 20 and one slot of shift on every second row PAIR
+    // put the 16 lanes of each ds_read_b128 group on 16 different slots.  (6x20 tiles: no such shift exists for their
+    // 10-tile rows; they keep the plain layout.)
+    static constexpr bool SWZ = TW_ == 16;
+    static constexpr int RP = SWZ ? RW + 2 : RW;
+    static constexpr int RAW_LDS = SWZ ? CQC * HH * RP : RAW_PAD;      // SWZ: slot RP - 1 of row 0 is free -> dump slot
     static constexpr int VPLANE = CQC * 32;                // float4 per position: [cq][tile]
     static constexpr int LDS_FLOAT4 = 16 * VPLANE;         // one transformed buffer (32 KB)
-    static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_PAD) * 16;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_LDS) * 16;
     static constexpr int DQ = 5;                           // weights: positions ahead
     static constexpr int DQB = 2;                          // transformed activations: positions ahead
     // staging schedule in events (two per position: 32 per unit, 128 matrix cycles apart)
@@ -113,17 +121,20 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     auto load_b = [&](int buf, int pos, int tb) { return sB[buf * LDSF + pos * VPLANE + tile_b + tb * 16]; };
 
     // ---- staging: raw tile ---------------------------------------------------------------------------------------
-    int r_hy[ITER_R], r_hx[ITER_R];
+    constexpr int RP = C::RP;
+    auto rowoff = [](int row) { return C::SWZ ? (row >> 1) & 1 : 0; };
+    int r_hyx[ITER_R], r_slot[ITER_R];       // (hy << 16 | hx) of the thread's raw pixels and their LDS slots
     unsigned r_rel[ITER_R];
 #pragma unroll
     for (int k = 0; k < ITER_R; ++k) {
         const int idx = tid + k * C::NTHREADS;
         const int cq = idx / (C::HH * RW);
         const int hp = idx - cq * (C::HH * RW);
-        r_hy[k] = hp / RW;
-        r_hx[k] = hp - r_hy[k] * RW;
-        const int prow = ((r_hy[k] - a.pad) >> a.ups) + a.pad, pcol = ((r_hx[k] - a.pad) >> a.ups) + a.pad;
+        const int hy = hp / RW, hx = hp - hy * RW;
+        r_hyx[k] = hy << 16 | hx;
+        const int prow = ((hy - a.pad) >> a.ups) + a.pad, pcol = ((hx - a.pad) >> a.ups) + a.pad;
         r_rel[k] = idx < C::RAW ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
+        r_slot[k] = idx < C::RAW ? (cq * C::HH + hy) * RP + hx + rowoff(hy) : C::SWZ ? RP - 1 : idx;
     }
     float4* sR = sB + 2 * LDSF;
     // transform piece of this thread: half h (xi rows 2h, 2h + 1) of (cq, tile); tiles past the end redo the last tile
@@ -131,10 +142,12 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     const int x_cq = (tid >> 5) & 3;
     const int x_tile = min(tid & 31, C::NTILES - 1);
     const int x_ty = x_tile / TX, x_tx = x_tile - x_ty * TX;
-    const int x_src = (x_cq * C::HH + 2 * x_ty) * RW + 2 * x_tx;       // raw index of the window's top-left pixel
+    const int x_src = (x_cq * C::HH + 2 * x_ty) * RP + 2 * x_tx;       // raw slot of the window's top-left pixel (before the row shift)
     // rows of the half-piece, branch-free: first xi = row A - row B, second xi = row B + sgn * row C
     //   h = 0: xi 0 = d0 - d2 (A = 0, B = 2), xi 1 = d1 + d2 (C = 1, sgn = +1);  h = 1: xi 2 = d2 - d1 (A = 2, B = 1), xi 3 = d1 - d3 (C = 3, sgn = -1)
-    const int x_ra = x_src + (x_h ? 2 : 0) * RW, x_rb = x_src + (x_h ? 1 : 2) * RW, x_rc = x_src + (x_h ? 3 : 1) * RW;
+    const int x_ia = x_h ? 2 : 0, x_ib = x_h ? 1 : 2, x_ic = x_h ? 3 : 1;
+    const int x_ra = x_src + x_ia * RP + rowoff(2 * x_ty + x_ia), x_rb = x_src + x_ib * RP + rowoff(2 * x_ty + x_ib),
+              x_rc = x_src + x_ic * RP + rowoff(2 * x_ty + x_ic);
     const float x_sg = x_h ? -1.f : 1.f;
     const dcx_f32x2 x_sgn = {x_sg, x_sg};
     const int x_dst = (8 * x_h) * VPLANE + x_cq * 32 + x_tile;         // + local position * VPLANE
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     };
 
     // ---- epilogue constants in LDS: alpha, beta2, output-transform table -----------------------------------------
-    float4* sP = sB + 2 * LDSF + C::RAW_PAD;
+    float4* sP = sB + 2 * LDSF + C::RAW_LDS;
     const int cq_pad = a.cout_pad >> 2;
     for (int i = tid; i < cq_pad; i += C::NTHREADS) {
         sP[i] = reinterpret_cast<const float4*>(a.alpha)[i];
@@ -222,9 +235,9 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         const int sy0 = cur.ty * C::TH - a.pad, sx0 = cur.tx * C::TW - a.pad;
 #pragma unroll
         for (int k = 0; k < ITER_R; ++k) {
-            const int ly = sy0 + r_hy[k], lx = sx0 + r_hx[k];
+            const int ly = sy0 + (r_hyx[k] >> 16), lx = sx0 + (r_hyx[k] & 0xffff);
             const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
-            sR[tid + k * C::NTHREADS] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
+            sR[r_slot[k]] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
         }
         __syncthreads();
 #pragma unroll
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         if (!n_interior) {
 #pragma unroll
             for (int k = 0; k < ITER_R; ++k) {
-                const int ly = nsy0 + r_hy[k], lx = nsx0 + r_hx[k];
+                const int ly = nsy0 + (r_hyx[k] >> 16), lx = nsx0 + (r_hyx[k] & 0xffff);
                 const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
                 roff[k] = inb ? r_rel[k] : 0x80000000u;
             }
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                 {
                     const int e = p * 2 + slot;          // staging event 0 .. 31
                     if (e >= C::E_RAW_LOAD && e < C::E_RAW_LOAD + ITER_R) rv[e - C::E_RAW_LOAD] = stage_fetch(rs_n, roff[e - C::E_RAW_LOAD]);
-                    if (e >= C::E_RAW_STORE && e < C::E_RAW_STORE + ITER_R) sR[tid + (e - C::E_RAW_STORE) * C::NTHREADS] = rv[e - C::E_RAW_STORE];
+                    if (e >= C::E_RAW_STORE && e < C::E_RAW_STORE + ITER_R) sR[r_slot[e - C::E_RAW_STORE]] = rv[e - C::E_RAW_STORE];
                     if (e >= C::E_XFORM && e < C::E_XFORM + 12) xform_event(vnext, e - C::E_XFORM);
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -26,6 +26,11 @@ def per_kernel(path, counter):
 
 
 def lib_name(rocprof_name):
+    m = re.search(r"DcxWino2hCfg<([^>]*)>", rocprof_name)
+    if m:   # <TH, TW, POOL, EPI>
+        f = [x.strip() for x in m.group(1).split(",")]
+        f[2] = "1" if f[2] == "true" else "0"
+        return "dcx_conv_wino2h_kernel<DcxWino2hCfg<" + ",".join(f[:3]) + ">>"
     m = re.search(r"DcxWino2Cfg<([^>]*)>", rocprof_name)
     if m:   # <TH, TW, POOL, EPI>
         f = [x.strip() for x in m.group(1).split(",")]
