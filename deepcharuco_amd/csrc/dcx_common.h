@@ -35,6 +35,7 @@ struct DcxConvArgs {
     float* out;            // C4 [N][out_cq_total][Hs][Ws][4]; Hs = Ho (or Ho/2 when pooled)
     const int* n_limit;    // optional device int: images n >= *n_limit are skipped
     unsigned long long* clk_probe;  // optional [4]: workgroup 0 stores {s_memtime, s_memrealtime} at start and end
+    int probe_u0;                   // first unit of workgroup 0's 20-unit probe window (tuning aid, DCX_PROBE_U0)
     // DCX_EPI_HEAT only
     const float* head_w;   // [cout_pad] weights of the 1x1 conv to one channel
     float head_b;

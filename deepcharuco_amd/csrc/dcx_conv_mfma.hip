@@ -388,6 +388,7 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
         else (void)hipMemset(g_clk_dev, 0, sizeof(unsigned long long) * kClkWords * kClkSlots);
     }
     if (g_clk_dev != nullptr && r.slot < kClkSlots) a.clk_probe = g_clk_dev + (size_t)kClkWords * r.slot;
+    { static int u0 = -1; if (u0 < 0) { const char* e = getenv("DCX_PROBE_U0"); u0 = e ? atoi(e) : 0; } a.probe_u0 = u0; }
     if (!r.e0 || !r.e1) return (int)hipErrorOutOfMemory;
     DCX_CHECK_HIP(hipEventRecord(r.e0, stream));
     const int rc = c->launch(a, stream);

@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         a.clk_probe[0] = __builtin_amdgcn_s_memtime();
         a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
     }
+#ifdef DCX_W2H_BLOCKTIMES      // tuning aid (tools/block_times.py): every workgroup's start / end time; overruns the launch's own probe slot
+    if (a.clk_probe != nullptr && tid == 0) a.clk_probe[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nch = a.cin / DCX_CCH;
     auto decode = [&](int wi) {
         DcxItem it;
@@ -260,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
             else { has_next = false; cn = c; }
         }
         const int buf = u & 1;
-        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[4 + 3 * u] = __builtin_amdgcn_s_memtime();
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[4 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
         __syncthreads();
-        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[5 + 3 * u] = __builtin_amdgcn_s_memtime();
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[5 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
 
         const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
         const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
 #pragma unroll
         for (int d = 0; d < DQ; ++d) a_c[d] = aq[16 + d];
 
-        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && u < 20) a.clk_probe[6 + 3 * u] = __builtin_amdgcn_s_memtime();
+        if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[6 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
         if (c == nch - 1 && (!ZERO || nch == 1)) {
             // ---- epilogue: output transform on the matrix cores, BN, ReLU (, pool), store -----------------------------
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // 8-pass MFMA result -> read as srcB: make the distance explicit
@@ -418,6 +421,9 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         }
 
         if (!has_next) {
+#ifdef DCX_W2H_BLOCKTIMES
+            if (a.clk_probe != nullptr && tid == 0) a.clk_probe[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
             if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
                 a.clk_probe[2] = __builtin_amdgcn_s_memtime();
                 a.clk_probe[3] = __builtin_amdgcn_s_memrealtime();
@@ -449,7 +455,8 @@ static int dcx_conv_wino2h_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
     const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 8 + 256;      // + alpha, beta2, output-transform table
     if (2 * lds > 160 * 1024) return DCX_E_SHAPE;                        // the point of this kernel is two workgroups per CU
-    const long resident = 2L * dcx_device_cu_count();
+    const int occ_env = dcx_occupancy_override();                        // tuning knob (DCX_OCC = 1: one workgroup per CU)
+    const long resident = (occ_env == 1 ? 1L : 2L) * dcx_device_cu_count();
     const long blocks = items < resident ? items : resident;
     a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
     static bool attr_set[DCX_MAX_DEVICES] = {};

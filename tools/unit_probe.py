@@ -34,5 +34,5 @@ for i in range(n):
     loop = t[:, 2] - t[:, 1]
     tail = np.r_[t[1:, 0] - t[:-1, 2], 0]      # after-loop (epilogue or nothing) until next unit's barrier
     clk = (w[2] - w[0]) / max(w[3] - w[1], 1) * 0.1
-    print(f"{i:2d} {name:40s} ms {ms[i]:.3f} clk {clk:.2f} units {valid}: loop {np.median(loop):.0f} (min {loop.min()} max {loop.max()}) "
+    print(f"{i:2d} {name:40s} ms {ms[i]:.3f} wg0 alive {(w[3] - w[1]) * 1e-5:.3f} ms = {w[2] - w[0]} cyc  clk {clk:.2f} units {valid}: loop {np.median(loop):.0f} (min {loop.min()} max {loop.max()}) "
           f"barrier med {np.median(barrier):.0f} max {barrier.max()}  tail {tail[:8].tolist()}")
