@@ -12,7 +12,7 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeepcharuco_amd.so")
+LIB_PATH = os.environ.get("DCX_LIB") or os.path.join(_HERE, "libdeepcharuco_amd.so")   # DCX_LIB: a variant build (kernel sweeps)
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib: Optional[C.CDLL] = None

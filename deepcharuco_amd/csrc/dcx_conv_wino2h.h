@@ -25,6 +25,20 @@
 #pragma once
 #include "dcx_conv_wino2.h"
 
+// schedule constants (overridable for sweeps: make EXTRA="-DDCX_W2H_E_STORE=11 -DDCX_W2H_E_XFORM=16")
+#ifndef DCX_W2H_DQ
+#define DCX_W2H_DQ 5
+#endif
+#ifndef DCX_W2H_DQB
+#define DCX_W2H_DQB 2
+#endif
+#ifndef DCX_W2H_E_STORE
+#define DCX_W2H_E_STORE 9
+#endif
+#ifndef DCX_W2H_E_XFORM
+#define DCX_W2H_E_XFORM 14
+#endif
+
 template <int TH_, int TW_, bool POOL_, int EPI_ = DCX_EPI_BNRELU>
 struct DcxWino2hCfg {
     static constexpr int TH = TH_, TW = TW_;
@@ -50,12 +64,12 @@ struct DcxWino2hCfg {
     static constexpr int VPLANE = CQC * 32;                // float4 per position: [cq][tile]
     static constexpr int LDS_FLOAT4 = 16 * VPLANE;         // one transformed buffer (32 KB)
     static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_LDS) * 16;
-    static constexpr int DQ = 5;                           // weights: positions ahead
-    static constexpr int DQB = 2;                          // transformed activations: positions ahead
+    static constexpr int DQ = DCX_W2H_DQ;                        // weights: positions ahead
+    static constexpr int DQB = DCX_W2H_DQB;                        // transformed activations: positions ahead
     // staging schedule in events (two per position: 32 per unit, 128 matrix cycles apart)
     static constexpr int E_RAW_LOAD = 0;
-    static constexpr int E_RAW_STORE = 9;
-    static constexpr int E_XFORM = 14;                     // mid barrier before this event; 12 transform events follow
+    static constexpr int E_RAW_STORE = DCX_W2H_E_STORE;
+    static constexpr int E_XFORM = DCX_W2H_E_XFORM;                   // mid barrier before this event; 12 transform events follow
     static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 32 && NTILES > 16, "tile must hold 17..32 2x2 tiles");
     static_assert(ITER_R <= 5 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM + 12 <= 32, "staging does not fit the schedule");
     static_assert(EPI == DCX_EPI_BNRELU, "plain BN + ReLU (+ pool) layers only");

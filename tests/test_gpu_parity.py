@@ -150,6 +150,8 @@ CONV_CASES = [
     ("A_8x32_ups_128to64", 2, 128, 64, 16, 16, 1, 1, 0, 3, True),
     ("P_ups_32x32_64to64", 3, 64, 64, 32, 32, 1, 1, 0, 3, True),
     ("P_ups_partial_10x12", 2, 64, 64, 10, 12, 1, 1, 0, 3, True),
+    ("W2H_600_items_xcd_walk", 6, 64, 64, 96, 128, 1, 0, 0, 3, True),     # > 2 x 256 work items: persistent XCD-aware walk
+    ("W2H_600_items_xcd_walk_pool", 5, 64, 128, 88, 120, 1, 0, 1, 3, True),  # partial tiles, two cout tiles, pooled
     ("k1_raw_65", 2, 256, 65, 30, 40, 0, 0, 0, 1, False),
     ("k1_raw_17", 2, 256, 17, 6, 9, 0, 0, 0, 1, False),
 ]
