@@ -261,11 +261,6 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         for (int x = 0; x < 12; ++x) xform_event(sB, x);
     }
 
-#ifdef DCX_W2H_DEBUG_DUMP
-    __syncthreads();
-    for (int i = tid; i < LDSF; i += C::NTHREADS) reinterpret_cast<float4*>(a.out)[i] = sB[i];     // transformed tile of unit 0
-    return;
-#endif
     int u = 0;
     auto run_unit = [&](auto zero_t) -> bool {
         constexpr bool ZERO = decltype(zero_t)::value;
@@ -344,9 +339,6 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][1]) : "v"(av), "v"(bv1));
                         }
                     }
-#ifdef DCX_W2H_DEBUG_NOP
-                    asm volatile("s_nop 7\n\ts_nop 7");
-#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

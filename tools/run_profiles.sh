@@ -27,6 +27,8 @@ if [ "$MODE" = collect ]; then
     DCX_XCD_WALK=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_fetch_flat" -o fetch -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_fetch_flat.log" 2>&1
     # bs=1 (the reference's own protocol): per-kernel times
     timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}_bs1" -o bs1 -- python $ROOT/tools/bs1_loop.py 60 1 > "$OUT/rocprof_bs1.log" 2>&1
+    (cd "$ROOT" && timeout 200 python tools/stream_bench.py > "$OUT/stream_bench.log" 2>&1)
+    (cd "$ROOT" && timeout 200 python tools/layer_table.py > "$OUT/layer_table.log" 2>&1)
     tail -1 "$OUT/bench.log"
 else
     cd "$ROOT"
@@ -41,5 +43,7 @@ else
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_sq/sq_results.db dcx_conv > profiles/r${R}_pmc_sq.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_lds/lds_results.db dcx_conv > profiles/r${R}_pmc_lds_valu.txt
     grep '^{' gpurun_out/bench.log > profiles/r${R}_bench_n1.json
+    grep -v "^\[\|Warning\|warn" gpurun_out/stream_bench.log > profiles/r${R}_stream_bench.txt
+    cp gpurun_out/layer_table.log profiles/r${R}_layer_table.txt
     ls -la profiles/
 fi
