@@ -273,7 +273,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         # 2/3; 2-D F(2x2,3x3): 4/9), so `achieved` (algorithmic FLOP / time, what the contract asks for) can exceed the
         # fp32-MFMA peak; `executed_*` is what the matrix pipe really ran.
         # (",PH>>": the phase variant for up-sampled inputs executes 4 of the 9 taps' worth of MACs, with pre-summed weights)
-        scale_of = lambda nm: 4.0 / 9.0 if ("wino2" in nm or ",PH>>" in nm) else 2.0 / 3.0 if "wino" in nm else 1.0
+        scale_of = lambda nm: (0.25 if "wino2p" in nm else 4.0 / 9.0 if ("wino2" in nm or ",PH>>" in nm)
+                               else 2.0 / 3.0 if "wino" in nm else 1.0)      # executed / algorithmic MACs of the kernel family
         exec_scale = scale_of(kname(dom_id))
         conv_exec = sum(a[0] * scale_of(kname(k)) for k, a in full.items())
         algo = ("winograd F(2x2,3x3): 4/9 of the algorithmic MACs are executed" if "wino2" in kname(dom_id)

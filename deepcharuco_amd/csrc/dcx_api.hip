@@ -93,6 +93,30 @@ std::vector<float> pack_conv_ups2(const float* w, int cout, int cin, int cout_pa
     return out;
 }
 
+// The same four phase kernels, each transformed for the 2-D Winograd F(2x2,2x2) of dcx_conv_wino2p.h:
+// [phase][xi*3 + nu][cin/4][cout_pad][4];  Wc[dy][.] = (Wp[dy][0], Wp[dy][0] + Wp[dy][1], Wp[dy][1]),
+// U[.][nu] = (Wc[0][nu], Wc[0][nu] + Wc[1][nu], Wc[1][nu]) -- fp32, columns first, one addition each.
+std::vector<float> pack_conv_ups2w(const float* w, int cout, int cin, int cout_pad) {
+    const int cq = cin / 4;
+    const std::vector<float> ph = pack_conv_ups2(w, cout, cin, cout_pad);      // [phase*4 + dy*2 + dx][cq][cout_pad][4]
+    std::vector<float> out((size_t)36 * cq * cout_pad * 4, 0.0f);
+    const size_t plane = (size_t)cq * cout_pad * 4;
+    for (int p = 0; p < 4; ++p)
+        for (size_t e = 0; e < plane; ++e) {
+            float wc[2][3];
+            for (int dy = 0; dy < 2; ++dy) {
+                const float g0 = ph[(size_t)(p * 4 + dy * 2 + 0) * plane + e], g1 = ph[(size_t)(p * 4 + dy * 2 + 1) * plane + e];
+                wc[dy][0] = g0; wc[dy][1] = g0 + g1; wc[dy][2] = g1;
+            }
+            for (int nu = 0; nu < 3; ++nu) {
+                out[(size_t)(p * 9 + 0 * 3 + nu) * plane + e] = wc[0][nu];
+                out[(size_t)(p * 9 + 1 * 3 + nu) * plane + e] = wc[0][nu] + wc[1][nu];
+                out[(size_t)(p * 9 + 2 * 3 + nu) * plane + e] = wc[1][nu];
+            }
+        }
+    return out;
+}
+
 // eval-mode BatchNorm2d as ATen's CPU inference path evaluates it: y = x * alpha + beta with
 // alpha = gamma * (1 / sqrt(var + eps)), beta = bn_bias - mean * alpha   (fp32 throughout).
 void fold_bn(const float* gamma, const float* bbeta, const float* mean, const float* var, int c, int c_pad,
@@ -118,6 +142,7 @@ struct DevLayer {       // one MFMA convolution's parameters on the device
     float* w_wino = nullptr;   // 3x3 + BN layers only
     float* w_wino2 = nullptr;  // 3x3 + BN layers only
     float* w_ups2 = nullptr;   // 3x3 + BN layers that read a x2 up-sampled input only
+    float* w_ups2w = nullptr;  // same layers, Winograd-transformed phase kernels
     float* bias = nullptr;
     float* alpha = nullptr;
     float* beta = nullptr;
@@ -135,6 +160,7 @@ void free_layer(DevLayer& l) {
     if (l.w_wino) (void)hipFree(l.w_wino);
     if (l.w_wino2) (void)hipFree(l.w_wino2);
     if (l.w_ups2) (void)hipFree(l.w_ups2);
+    if (l.w_ups2w) (void)hipFree(l.w_ups2w);
     if (l.bias) (void)hipFree(l.bias);
     if (l.alpha) (void)hipFree(l.alpha);
     if (l.beta) (void)hipFree(l.beta);
@@ -163,6 +189,7 @@ int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out, bool
         if (rc == 0 && ks == 3) rc = upload(pack_conv_wino(h.w, cout, cin, l.cout_pad), &l.w_wino);
         if (rc == 0 && ks == 3) rc = upload(pack_conv_wino2(h.w, cout, cin, l.cout_pad), &l.w_wino2);
         if (rc == 0 && ks == 3 && ups_input) rc = upload(pack_conv_ups2(h.w, cout, cin, l.cout_pad), &l.w_ups2);
+        if (rc == 0 && ks == 3 && ups_input) rc = upload(pack_conv_ups2w(h.w, cout, cin, l.cout_pad), &l.w_ups2w);
     }
     if (rc != 0) { free_layer(l); return rc; }
     *out = l;
@@ -259,7 +286,7 @@ DcxConvArgs conv_args(const DevLayer& l, const float* in, int n, int in_cq_total
                       int ups, int pad, float* out, int out_cq_total, const int* n_limit) {
     DcxConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.w_wino2 = l.w_wino2; a.w_ups2 = l.w_ups2; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
+    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.w_wino2 = l.w_wino2; a.w_ups2 = l.w_ups2; a.w_ups2w = l.w_ups2w; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
     a.n_limit = n_limit;
     a.n = n; a.in_cq_total = in_cq_total; a.in_cq_off = in_cq_off; a.cin = l.cin;
     a.hin = hin; a.win = win; a.ups = ups; a.pad = pad;

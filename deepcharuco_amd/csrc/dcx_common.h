@@ -29,6 +29,8 @@ struct DcxConvArgs {
     const float* w_wino2;  // nullable; same layers: F(2x2,3x3)-transformed weights [xi*4 + nu][cin/4][cout_pad][4] (dcx_conv_wino2.h)
     const float* w_ups2;   // nullable; 3x3 + BN layers read through a nearest x2 up-sampling: the four phases' pre-summed 2x2 kernels
                            // [phase][tap][cin/4][cout_pad][4] (dcx_conv_mfma.h, PH variant)
+    const float* w_ups2w;  // nullable; same layers: the phases' 2x2 kernels F(2x2,2x2)-transformed
+                           // [phase][xi*3 + nu][cin/4][cout_pad][4] (dcx_conv_wino2p.h)
     const float* bias;     // [cout_pad]
     const float* alpha;    // [cout_pad]  gamma / sqrt(var + eps)
     const float* beta;     // [cout_pad]  bn_beta - mean * alpha

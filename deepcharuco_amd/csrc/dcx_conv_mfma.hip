@@ -3,6 +3,7 @@
 #include "dcx_conv_wino.h"
 #include "dcx_conv_wino2.h"
 #include "dcx_conv_wino2h.h"
+#include "dcx_conv_wino2p.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -51,6 +52,12 @@ struct CfgEntry {
     { 64, 128, TH, TW, 3, POOL, DCX_EPI_BNRELU, 8, 0, 1, 3, 0,                                               \
       &dcx_conv_wino2h_launch_cfg<DcxWino2hCfg<TH, TW, (POOL) != 0>>,                                      \
       "dcx_conv_wino2h_kernel<DcxWino2hCfg<" #TH "," #TW "," #POOL ">>" }
+
+// phase variant as a 2-D Winograd F(2x2,2x2) per phase (dcx_conv_wino2p.h): th x tw is a LOW-RESOLUTION tile of one phase
+#define DCX_W2PCFG(TH, TW, EPI)                                                                       \
+    { 64, 128, TH, TW, 3, 0, EPI, 5, 0, 1, 4, 1,                                                             \
+      &dcx_conv_wino2p_launch_cfg<DcxWino2pCfg<TH, TW, EPI>>,                                              \
+      "dcx_conv_wino2p_kernel<DcxWino2pCfg<" #TH "," #TW "," #EPI ">>" }
 
 #define DCX_W2CFG_G(TH, TW, G)                                                                        \
     { 64, 256, TH, TW, 3, 0, DCX_EPI_BNRELU, 16, 0, G, 2, 0,                                                \
@@ -119,11 +126,20 @@ const CfgEntry kCfgs[] = {
     DCX_W2HCFG(8, 16, 1),
     DCX_W2HCFG(6, 20, 0),     // 3 x 10 tiles: 30x40 and 60x80 maps without padding, RefineNet's 18/20-pixel maps at 83-90 %
     DCX_W2HCFG(6, 20, 1),
+    // phase variant + F(2x2,2x2) per phase: 2.25 multiply-adds per output pixel (the layer as written: 9)
+    DCX_W2PCFG(8, 16, DCX_EPI_BNRELU),
+    DCX_W2PCFG(8, 16, DCX_EPI_HEAT),
 };
 
 int dcx_wino2h_mode() {   // DCX_WINO2H: 0 = never, 1 = cost model (default), 2 = whenever it can run the layer (A/B runs)
     static int v = -1;
     if (v < 0) { const char* e = getenv("DCX_WINO2H"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+int dcx_ups2w_mode() {   // DCX_UPS2W: 0 = never, 1 = cost model (default), 2 = whenever it can run the layer (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DCX_UPS2W"); v = e ? atoi(e) : 1; }
     return v;
 }
 
@@ -185,7 +201,8 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         for (const CfgEntry& c : kCfgs)
             if (strcmp(c.name, force) == 0 && c.ks == ks && c.pool == pool && c.epi == epi && cout_pad % c.cout_tile == 0 &&
                 (c.group == 1 || (allow_group && ho <= c.th && wo <= c.tw)) && (!c.ups2 || ups == 1) &&
-                (c.wino != 3 || (cout_pad <= 128 && cin >= 2 * DCX_CCH)))
+                (c.wino != 3 || (cout_pad <= 128 && cin >= 2 * DCX_CCH)) &&
+                (c.wino != 4 || (cin >= 2 * DCX_CCH && (epi != DCX_EPI_HEAT || cout_pad == 64))))
                 return &c;
     }
     for (const CfgEntry& c : kCfgs) {
@@ -211,6 +228,16 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         if (c.ups2) {      // phase variant: only for layers reading a x2 up-sampled input; tiles are low-resolution, x4 items,
                            // 8 k-steps (4 taps x 2) per 16-channel unit
             if (ups != 1 || !dcx_ups2_enabled() || dcx_deterministic_enabled()) continue;
+            if (c.wino == 4) {   // Winograd per phase: 9 x 8 MFMAs of 32 cycles per unit, two co-resident workgroups per CU
+                if (dcx_ups2w_mode() == 0 || !dcx_wino2_enabled() || cin < 2 * DCX_CCH || (epi == DCX_EPI_HEAT && cout_pad != 64)) continue;
+                const long wt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);
+                const double items_w = (double)n * (cout_pad / c.cout_tile) * wt * 4;
+                const double item_cost_w = (double)(cin / DCX_CCH) * (72 * 32.0 + 500.0) + 2400.0;
+                double cost_w = (double)(((long)items_w + n_cu - 1) / n_cu) * item_cost_w;
+                if (dcx_ups2w_mode() == 2) cost_w = 1.0;
+                if (best == nullptr || cost_w < best_cost) { best_cost = cost_w; best = &c; }
+                continue;
+            }
             const long lt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);
             const double items_p = (double)n * (cout_pad / c.cout_tile) * lt * 4;
             const int units_p = cin / DCX_CCH;

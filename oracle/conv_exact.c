@@ -18,6 +18,7 @@
  */
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 void dcx_oracle_fold_bn(const float* gamma, const float* bbeta, const float* mean, const float* var, int c,
                         float* alpha, float* beta) {
@@ -245,4 +246,95 @@ void dcx_oracle_conv_ups2_exact(const float* x, int n, int cin, int h, int w, co
                     y[(((size_t)b * cout + co) * ho + oy) * wo + ox] =
                         fmaxf(fmaf(acc, alpha[co], fmaf(bias[co], alpha[co], beta[co])), 0.0f);
                 }
+}
+
+/* Phase variant as a 2-D Winograd F(2x2,2x2) per phase (deepcharuco_amd/csrc/dcx_conv_wino2p.h): 3x3 convolution (pad 1)
+ * over a nearest-x2 up-sampled input, computed on the low-resolution tensor x [n][cin][h][w].
+ *   Wp[a][b][dy][dx]: the 3x3 kernel's rows / columns pre-summed exactly as in dcx_oracle_conv_ups2_exact above;
+ *   Wc[dy] = (Wp[dy][0], Wp[dy][0] + Wp[dy][1], Wp[dy][1]);  U[.][nu] = (Wc[0][nu], Wc[0][nu] + Wc[1][nu], Wc[1][nu]);
+ *   per phase (a, b) and 2x2 tile of low-resolution positions (y0, x0), y0, x0 even:
+ *     d[r][s] = x[y0 - (1-a) + r][x0 - (1-b) + s] (0 outside);  t[0] = d[0] - d[1], t[1] = d[1], t[2] = d[2] - d[1] (per column s);
+ *     v[xi][0] = t[xi][0] - t[xi][1], v[xi][1] = t[xi][1], v[xi][2] = t[xi][2] - t[xi][1];
+ *     m[p = 3 xi + nu] = 0; for chunk c0 (16 cin) / j in 0..3 / g in 0..3: m = fmaf(U[ci], v[ci], m), ci = c0 + 4 g + j;
+ *     y_k (k = 2 i + j) = 0; for p in 0..8: y_k = fmaf(AT[i][xi] * AT[j][nu], m[p], y_k), AT = [[1,1,0],[0,1,1]];
+ *     out[2 (y0 + i) + a][2 (x0 + j) + b] = max(fmaf(y_k, alpha, fmaf(bias, alpha, beta)), 0). */
+void dcx_oracle_conv_ups2w_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                                 const float* alpha, const float* beta, int cout, float* y) {
+    static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};
+    static const float AT[2][3] = {{1.f, 1.f, 0.f}, {0.f, 1.f, 1.f}};
+    const int ho = 2 * h, wo = 2 * w;
+    const int ty_n = (h + 1) / 2, tx_n = (w + 1) / 2;
+    /* transformed weights U[phase][p][co][ci] */
+    float* U = (float*)malloc(sizeof(float) * 36 * (size_t)cout * cin);
+    for (int ph = 0; ph < 4; ++ph)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci) {
+                const int pa = ph >> 1, pb = ph & 1;
+                const float* g = wt + ((size_t)co * cin + ci) * 9;
+                float wp[2][2], wc[2][3];
+                for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx) {
+                        float r[3];
+                        for (int kx = 0; kx < 3; ++kx) {
+                            r[kx] = g[lo[pa][dy] * 3 + kx];
+                            for (int ky = lo[pa][dy] + 1; ky <= hi[pa][dy]; ++ky) r[kx] = r[kx] + g[ky * 3 + kx];
+                        }
+                        float wv = r[lo[pb][dx]];
+                        for (int kx = lo[pb][dx] + 1; kx <= hi[pb][dx]; ++kx) wv = wv + r[kx];
+                        wp[dy][dx] = wv;
+                    }
+                for (int dy = 0; dy < 2; ++dy) { wc[dy][0] = wp[dy][0]; wc[dy][1] = wp[dy][0] + wp[dy][1]; wc[dy][2] = wp[dy][1]; }
+                for (int nu = 0; nu < 3; ++nu) {
+                    U[((size_t)(ph * 9 + 0 + nu) * cout + co) * cin + ci] = wc[0][nu];
+                    U[((size_t)(ph * 9 + 3 + nu) * cout + co) * cin + ci] = wc[0][nu] + wc[1][nu];
+                    U[((size_t)(ph * 9 + 6 + nu) * cout + co) * cin + ci] = wc[1][nu];
+                }
+            }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < n; ++b)
+        for (int ty = 0; ty < ty_n; ++ty) {
+            float* V = (float*)malloc(sizeof(float) * 9 * (size_t)cin);
+            for (int tx = 0; tx < tx_n; ++tx)
+                for (int ph = 0; ph < 4; ++ph) {
+                    const int pa = ph >> 1, pb = ph & 1;
+                    const int y0 = 2 * ty, x0 = 2 * tx;
+                    for (int ci = 0; ci < cin; ++ci) {
+                        float d[3][3], t[3][3];
+                        for (int r = 0; r < 3; ++r)
+                            for (int s = 0; s < 3; ++s) {
+                                const int iy = y0 - (1 - pa) + r, ix = x0 - (1 - pb) + s;
+                                d[r][s] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? x[(((size_t)b * cin + ci) * h + iy) * w + ix] : 0.0f;
+                            }
+                        for (int s = 0; s < 3; ++s) { t[0][s] = d[0][s] - d[1][s]; t[1][s] = d[1][s]; t[2][s] = d[2][s] - d[1][s]; }
+                        for (int xi = 0; xi < 3; ++xi) {
+                            V[(size_t)(xi * 3 + 0) * cin + ci] = t[xi][0] - t[xi][1];
+                            V[(size_t)(xi * 3 + 1) * cin + ci] = t[xi][1];
+                            V[(size_t)(xi * 3 + 2) * cin + ci] = t[xi][2] - t[xi][1];
+                        }
+                    }
+                    for (int co = 0; co < cout; ++co) {
+                        float m[9];
+                        for (int p = 0; p < 9; ++p) {
+                            const float* u = U + ((size_t)(ph * 9 + p) * cout + co) * cin;
+                            const float* v = V + (size_t)p * cin;
+                            float acc = 0.0f;
+                            for (int c0 = 0; c0 < cin; c0 += 16)
+                                for (int j = 0; j < 4; ++j)
+                                    for (int g = 0; g < 4; ++g) acc = fmaf(u[c0 + 4 * g + j], v[c0 + 4 * g + j], acc);
+                            m[p] = acc;
+                        }
+                        for (int i = 0; i < 2; ++i)
+                            for (int j = 0; j < 2; ++j) {
+                                float yk = 0.0f;
+                                for (int p = 0; p < 9; ++p) yk = fmaf(AT[i][p / 3] * AT[j][p % 3], m[p], yk);
+                                const int ly = y0 + i, lx = x0 + j;
+                                if (ly < h && lx < w)
+                                    y[(((size_t)b * cout + co) * ho + 2 * ly + pa) * wo + 2 * lx + pb] =
+                                        fmaxf(fmaf(yk, alpha[co], fmaf(bias[co], alpha[co], beta[co])), 0.0f);
+                            }
+                    }
+                }
+            free(V);
+        }
+    free(U);
 }

@@ -27,9 +27,10 @@ def lib():
 def conv_exact(x, wt, bias, bn=None, pad=1, ups=False, pool=False, wino=False):
     """x NCHW float32; bn = (gamma, beta, mean, var) or None (raw).  Returns NCHW float32.
     wino=True: the summation order of the 1-D Winograd F(2,3) kernel, wino=2: of the 2-D F(2x2,3x3) kernel
-    (3x3 + BN layers only), wino=4: of its half-tile variant (dcx_conv_wino2h.h); wino=3: the phase variant of the direct kernel (3x3 pad 1 + BN over an up-sampled input)."""
+    (3x3 + BN layers only), wino=4: of its half-tile variant (dcx_conv_wino2h.h); wino=3: the phase variant of the direct kernel (3x3 pad 1 + BN over an up-sampled input), wino=5: the phase variant with
+    F(2x2,2x2) per phase (dcx_conv_wino2p.h)."""
     x = np.ascontiguousarray(x, np.float32)
-    if wino == 3:
+    if wino in (3, 5):
         assert ups and bn is not None and pad == 1 and not pool
         wt = np.ascontiguousarray(wt, np.float32)
         bias = np.ascontiguousarray(bias, np.float32)
@@ -41,7 +42,8 @@ def conv_exact(x, wt, bias, bn=None, pad=1, ups=False, pool=False, wino=False):
         g, be, mu, var = [np.ascontiguousarray(t, np.float32) for t in bn]
         alpha, beta = np.empty(cout, np.float32), np.empty(cout, np.float32)
         lib().dcx_oracle_fold_bn(p(g), p(be), p(mu), p(var), cout, p(alpha), p(beta))
-        lib().dcx_oracle_conv_ups2_exact(p(x), n, cin, h, w, p(wt), p(bias), p(alpha), p(beta), cout, p(y))
+        fn = lib().dcx_oracle_conv_ups2_exact if wino == 3 else lib().dcx_oracle_conv_ups2w_exact
+        fn(p(x), n, cin, h, w, p(wt), p(bias), p(alpha), p(beta), cout, p(y))
         return y
     if ups:
         x = np.ascontiguousarray(x.repeat(2, axis=2).repeat(2, axis=3))

@@ -115,7 +115,8 @@ def _conv_layer(x_nchw, w, b, bn, pad, ups, pool, ks=3):
 
 def _family(kernel_name):
     """Which exact-order restatement (oracle/conv_exact.c) a kernel instantiation follows."""
-    return 3 if ",PH>>" in kernel_name else 4 if "wino2h" in kernel_name else 2 if "wino2" in kernel_name else 1 if "wino" in kernel_name else 0
+    return (5 if "wino2p" in kernel_name else 3 if ",PH>>" in kernel_name else 4 if "wino2h" in kernel_name
+            else 2 if "wino2" in kernel_name else 1 if "wino" in kernel_name else 0)
 
 
 def _conv_ref(x, w, b, bn, pad, ups, pool):

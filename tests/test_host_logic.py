@@ -211,7 +211,8 @@ def test_tile_cost_model_choices():
     """The host-side tile selection (csrc/dcx_conv_mfma.hip: pick) is a cost model; these are the choices the design
     relies on: the half-tile 2-D Winograd kernel (two workgroups per CU) for the 64/128-cout 3x3 layers, the big-tile 2-D
     Winograd kernel where the half-tile one cannot run (512 couts: the per-channel constants of two workgroups do not fit
-    the LDS), the phase variant for layers behind an up-sampling, the direct kernel for 1x1 and in deterministic mode."""
+    the LDS), the phase variants for layers behind an up-sampling (with F(2x2,2x2) per phase where the low-resolution map fills the
+    tiles), the direct kernel for 1x1 and in deterministic mode."""
     from deepcharuco_amd import _lib
     L = _lib.lib()
     name = lambda *a: L.dcx_conv_pick_name(*a).decode()
@@ -221,8 +222,9 @@ def test_tile_cost_model_choices():
     assert "DcxWino2hCfg<8,16,0>" in name(32, 64, 120, 160, 64, 3, 0, 0)                 # conv2a
     assert "DcxWino2hCfg<6,20,0>" in name(512, 64, 18, 18, 128, 3, 0, 0)                 # RefineNet conv2a: 18x18 map in 3 tiles of 6x20
     assert "DcxWino2Cfg<6,40,0>" in name(32, 128, 30, 40, 512, 3, 0, 0)                  # fused heads' 3x3 (512 couts): big tiles
-    assert "DCX_EPI_HEAT,PH>>" in name_ups(512, 64, 64, 64, 64, 3, 0, 2, 1)              # RefineNet head behind the x2 up-sampling
-    assert ",PH>>" in name_ups(512, 128, 32, 32, 64, 3, 0, 0, 1)                         # conv5a
+    assert name_ups(512, 64, 64, 64, 64, 3, 0, 2, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,16,DCX_EPI_HEAT>>"    # RefineNet head behind the x2 up-sampling: phases + F(2x2,2x2)
+    assert name_ups(512, 128, 32, 32, 64, 3, 0, 0, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,16,DCX_EPI_BNRELU>>"  # conv5a
+    assert ",PH>>" in name_ups(16, 128, 32, 32, 64, 3, 0, 0, 1)                          # conv5a at bs=1 (16 patches): the small-tile phase kernel
     assert "DcxWino2Cfg<16,16,0,DCX_EPI_HEAT>" in name(512, 64, 64, 64, 64, 3, 0, 2)     # the same head without the phase variant
     assert "<1,4,2,2,1,256,1,0,DCX_EPI_RAW>" in name(32, 256, 1, 1200, 65, 1, 0, 1)
     L.dcx_set_deterministic(1)
@@ -258,8 +260,12 @@ def test_c_restatement_agrees_with_torch_fp32():
             ref = F.relu(F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5))
         if pool:
             ref = F.max_pool2d(ref, 2, 2)
-        # the direct order, and for 3x3 + BN layers with cin % 16 == 0 also the 1-D F(2,3) and 2-D F(2x2,3x3) Winograd orders
-        for wino in ([0, 1, 2] if (ks == 3 and has_bn and cin % 16 == 0) else [0]):
+        # the direct order, and for 3x3 + BN layers with cin % 16 == 0 also the 1-D F(2,3) and the two 2-D F(2x2,3x3) Winograd
+        # orders; layers behind an up-sampling: the two phase variants
+        fams = [0]
+        if ks == 3 and has_bn and cin % 16 == 0:
+            fams = [0, 3, 5] if ups else [0, 1, 2, 4]
+        for wino in fams:
             got = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
                              pad=pad, ups=ups, pool=pool, wino=wino)
             assert got.shape == tuple(ref.shape)
