@@ -29,10 +29,10 @@
 #include "dcx_conv_wino2h.h"
 
 #ifndef DCX_W2P_DQ
-#define DCX_W2P_DQ 4
+#define DCX_W2P_DQ 3
 #endif
 #ifndef DCX_W2P_DQB
-#define DCX_W2P_DQB 2
+#define DCX_W2P_DQB 1
 #endif
 #ifndef DCX_W2P_E_STORE
 #define DCX_W2P_E_STORE 6
@@ -41,7 +41,12 @@
 #define DCX_W2P_E_XFORM 10
 #endif
 #ifndef DCX_W2P_OCC
-#define DCX_W2P_OCC 2
+#define DCX_W2P_OCC 3
+#endif
+#ifdef DCX_W2P_NUM_VGPR
+#define DCX_W2P_ATTR __attribute__((amdgpu_num_vgpr(DCX_W2P_NUM_VGPR)))
+#else
+#define DCX_W2P_ATTR
 #endif
 
 template <int TH_, int TW_, int EPI_ = DCX_EPI_BNRELU>
@@ -69,14 +74,14 @@ struct DcxWino2pCfg {
     // staging schedule in events (two per position: 18 per unit, 128 matrix cycles apart)
     static constexpr int E_RAW_LOAD = 0;
     static constexpr int E_RAW_STORE = DCX_W2P_E_STORE;
-    static constexpr int E_XFORM = DCX_W2P_E_XFORM;        // mid barrier before this event; 7 transform events follow
+    static constexpr int E_XFORM = DCX_W2P_E_XFORM;        // mid barrier before this event; 6 transform events follow
     static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 32 && NTILES > 16 && TX == 8, "tile: 17..32 2x2 tiles, 8 per row");
-    static_assert(ITER_R <= 3 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM % 2 == 0 && E_XFORM + 7 <= 2 * NP, "staging does not fit the schedule");
+    static_assert(ITER_R <= 3 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM % 2 == 0 && E_XFORM + 6 <= 2 * NP, "staging does not fit the schedule");
     static_assert(EPI == DCX_EPI_BNRELU || EPI == DCX_EPI_HEAT, "BN + ReLU, optionally followed by the RefineNet head");
 };
 
 template <class C>
-__global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const DcxConvArgs a) {
+__global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p_kernel(const DcxConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sB[];
     constexpr int TX = C::TX, RW = C::RW, RP = C::RP, ITER_R = C::ITER_R, LDSF = C::LDS_FLOAT4, CQC = C::CQC, VPLANE = C::VPLANE;
     constexpr int DQ = C::DQ, DQB = C::DQB, NP = C::NP;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
 
     // ---- staging: raw tile [cq][hy][hx] of the LOW-RESOLUTION tensor, origin (ty TH - (1-a), tx TW - (1-b)) -------------
     auto rowoff = [](int row) { return (row >> 1) & 1; };
-    int r_hyx[ITER_R], r_slot[ITER_R];
+    int r_hyx = 0, r_slot[ITER_R];          // r_hyx: (hy << 5 | hx) of the thread's raw pixels, 10 bits each
     unsigned r_rel[ITER_R];
 #pragma unroll
     for (int k = 0; k < ITER_R; ++k) {
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
         const int cq = idx / (C::HH * RW);
         const int hp = idx - cq * (C::HH * RW);
         const int hy = hp / RW, hx = hp - hy * RW;
-        r_hyx[k] = hy << 16 | hx;
+        r_hyx |= (hy << 5 | hx) << (10 * k);
         r_rel[k] = idx < C::RAW ? (unsigned)((cq * a.hin + hy) * a.win + hx) * 16u : 0x80000000u;
         r_slot[k] = idx < C::RAW ? (cq * C::HH + hy) * RP + hx + rowoff(hy) : RP - 1;
     }
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
         const int sy0 = cur.ty * C::TH - pad_y(cur), sx0 = cur.tx * C::TW - pad_x(cur);
 #pragma unroll
         for (int k = 0; k < ITER_R; ++k) {
-            const int ly = sy0 + (r_hyx[k] >> 16), lx = sx0 + (r_hyx[k] & 0xffff);
+            const int ly = sy0 + ((r_hyx >> (10 * k + 5)) & 31), lx = sx0 + ((r_hyx >> (10 * k)) & 31);
             const bool inb = (unsigned)ly < (unsigned)a.hin && (unsigned)lx < (unsigned)a.win;
             sR[r_slot[k]] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
         }
@@ -252,9 +257,13 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
             else { has_next = false; cn = c; }
         }
         const int buf = u & 1;
+#ifdef DCX_W2P_PROBES      // per-unit time stamps (tools/unit_probe.py); off by default: they cost SGPRs this kernel does not have to spare
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[4 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef DCX_W2P_PROBES
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[5 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
+#endif
 
         const __amdgpu_buffer_rsrc_t rs_n = unit_rsrc(nxt, cn);
         const int nsy0 = nxt.ty * C::TH - pad_y(nxt), nsx0 = nxt.tx * C::TW - pad_x(nxt);
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
         if (!n_interior) {
 #pragma unroll
             for (int k = 0; k < ITER_R; ++k) {
-                const int ly = nsy0 + (r_hyx[k] >> 16), lx = nsx0 + (r_hyx[k] & 0xffff);
+                const int ly = nsy0 + ((r_hyx >> (10 * k + 5)) & 31), lx = nsx0 + ((r_hyx >> (10 * k)) & 31);
                 const bool inb = (unsigned)ly < (unsigned)a.hin && (unsigned)lx < (unsigned)a.win;
                 roff[k] = inb ? r_rel[k] : 0x80000000u;
             }
@@ -324,7 +333,9 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
 #pragma unroll
         for (int d = 0; d < DQ; ++d) a_c[d] = aq[NP + d];
 
+#ifdef DCX_W2P_PROBES
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[6 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
+#endif
         if (c == nch - 1 && (!ZERO || nch == 1)) {
             // ---- epilogue: output transform on the matrix cores, BN, ReLU, store at stride 2 (or the head) -----------------
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
@@ -332,40 +343,57 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
             for (int p = 0; p < NP; ++p) { asm volatile("" : "+a"(acc[p][0])); asm volatile("" : "+a"(acc[p][1])); }
             const int pa = cur.ph >> 1, pb = cur.ph & 1;
             const unsigned plane = (unsigned)(a.ho * a.wo);
-            const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 4 + g4;          // the lane's output channel quad
+            int lne = lane;
+            asm volatile("" : "+v"(lne));   // opaque copy: the epilogue's lane arithmetic must not be hoisted out of the unit loop (VGPR budget)
+            const int g4e = lne >> 4, l15e = lne & 15;
+            const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 4 + g4e;         // the lane's output channel quad
             char* obase = reinterpret_cast<char*>(a.out)
                         + ((size_t)cur.n * a.out_cq_total + a.out_cq_off + cq) * (size_t)plane * 16;
             float cf[NP];
             {
-                const float4* tp = reinterpret_cast<const float4*>(sT + (lane & 3) * 16);
+                const float4* tp = reinterpret_cast<const float4*>(sT + (lne & 3) * 16);
                 const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                 cf[0] = t0.x; cf[1] = t0.y; cf[2] = t0.z; cf[3] = t0.w; cf[4] = t1.x; cf[5] = t1.y; cf[6] = t1.z; cf[7] = t1.w; cf[8] = t2.x;
             }
-            dcx_f32x4 e[2][4];        // e[tb][i][k]: output k of cout 4 * cq + i for the lane's tile tb * 16 + l15
+            const float4 al = sP[cq], be = sP[cq_pad + cq];
+            const dcx_f32x2 al01 = {al.x, al.y}, al23 = {al.z, al.w}, be01 = {be.x, be.y}, be23 = {be.z, be.w};
+            float hsum[2][4];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
+            for (int tb = 0; tb < 2; ++tb) {
+                // one tile block at a time (four interleaved chains: dependent accumulations stay >= 4 instructions apart)
+                dcx_f32x4 e[2][4];        // e[tb][i][k]: output k of cout 4 * cq + i for the lane's tile tb * 16 + l15
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
+                for (int p = 0; p < NP; ++p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (p == 0) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=v"(e[tb][i]) : "v"(cf[0]), "a"(acc[0][tb][i]));
                         else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(e[tb][i]) : "v"(cf[p]), "a"(acc[p][tb][i]));
                     }
                 }
-            }
-            asm volatile("s_nop 7" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]),
-                                     "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[1][2]), "+v"(e[1][3]));
-            const float4 al = sP[cq], be = sP[cq_pad + cq];
-            const dcx_f32x2 al01 = {al.x, al.y}, al23 = {al.z, al.w}, be01 = {be.x, be.y}, be23 = {be.z, be.w};
-            float hsum[2][4];
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                const int qt = tb * 16 + l15;
+                asm volatile("s_nop 7" : "+v"(e[tb][0]), "+v"(e[tb][1]), "+v"(e[tb][2]), "+v"(e[tb][3]));
+                __builtin_amdgcn_sched_barrier(0);
+                const int qt = tb * 16 + l15e;
                 const int qty = qt / TX, qtx = qt - qty * TX;
                 const int ly0 = cur.ty * C::TH + 2 * qty, lx0 = cur.tx * C::TW + 2 * qtx;     // low-resolution position of output k = 0
                 const bool qok = qt < C::NTILES && cq < a.cout_quads;
                 const bool okr0 = qok && ly0 < a.hin, okr1 = qok && ly0 + 1 < a.hin;
                 const bool okc0 = lx0 < a.win, okc1 = lx0 + 1 < a.win;
+                if (C::EPI == DCX_EPI_HEAT) {
+                    // head: h[k] = sum over the lane's four couts of relu(bn(e)) * head_w, an fmaf chain in cout order; nothing is stored
+                    const float4 hw = cq < a.cout_quads ? sP[2 * cq_pad + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float h[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float ai = i == 0 ? al.x : i == 1 ? al.y : i == 2 ? al.z : al.w;
+                        const float bi = i == 0 ? be.x : i == 1 ? be.y : i == 2 ? be.z : be.w;
+                        const float wi = i == 0 ? hw.x : i == 1 ? hw.y : i == 2 ? hw.z : hw.w;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) h[k] = fmaf(dcx_vmax(fmaf(e[tb][i][k], ai, bi), 0.f), wi, h[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hsum[tb][k] = h[k];
+                    continue;
+                }
                 dcx_f32x2 bn[4][2];     // [i][k / 2]
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -383,16 +411,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
                     y[k].x = dcx_vmax(y[k].x, 0.f); y[k].y = dcx_vmax(y[k].y, 0.f);
                     y[k].z = dcx_vmax(y[k].z, 0.f); y[k].w = dcx_vmax(y[k].w, 0.f);
                 }
-                if (C::EPI == DCX_EPI_HEAT) {
-                    const float4 hw = cq < a.cout_quads ? sP[2 * cq_pad + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float h = 0.f;
-                        h = fmaf(y[k].x, hw.x, h); h = fmaf(y[k].y, hw.y, h);
-                        h = fmaf(y[k].z, hw.z, h); h = fmaf(y[k].w, hw.w, h);
-                        hsum[tb][k] = h;
-                    }
-                } else {
+                {
                     // output k = (i, j) of the tile is low-resolution pixel (ly0 + i, lx0 + j) -> pixel (2 (ly0 + i) + a, 2 (lx0 + j) + b)
                     char* dst = obase + (size_t)((unsigned)((2 * ly0 + pa) * a.wo + 2 * lx0 + pb) * 16u);
                     if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = y[0];
@@ -415,16 +434,22 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) void dcx_conv_wino2p_kernel(const
                     }
                 __syncthreads();                                   // every wave is done reading this unit's operands
                 float* scr = reinterpret_cast<float*>(sB + buf * LDSF);    // [wave][tile 32][k 4]
-                if (g4 == 0) {
+                {
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    if ((ln >> 4) == 0) {
 #pragma unroll
-                    for (int tb = 0; tb < 2; ++tb)
-                        *reinterpret_cast<float4*>(scr + ((wm * 32 + tb * 16 + l15) * 4)) = make_float4(t[tb][0], t[tb][1], t[tb][2], t[tb][3]);
+                        for (int tb = 0; tb < 2; ++tb)
+                            *reinterpret_cast<float4*>(scr + ((wm * 32 + tb * 16 + ln) * 4)) = make_float4(t[tb][0], t[tb][1], t[tb][2], t[tb][3]);
+                    }
                 }
                 __syncthreads();
                 float best = -INFINITY;
                 int besti = 0x7fffffff;
                 if (wm == 0) {
-                    const int qt = lane & 31, kh = lane >> 5;        // lane: tile qt, outputs k = 2 kh, 2 kh + 1 (row i = kh)
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));       // opaque: keeps hipcc from hoisting this lane arithmetic out of the unit loop (VGPRs)
+                    const int qt = ln & 31, kh = ln >> 5;            // lane: tile qt, outputs k = 2 kh, 2 kh + 1 (row i = kh)
                     const int qty = qt / TX, qtx = qt - qty * TX;
                     const int ly = cur.ty * C::TH + 2 * qty + kh, lx0 = cur.tx * C::TW + 2 * qtx;
 #pragma unroll

@@ -297,6 +297,14 @@ def test_conv_kernels_do_not_spill():
         assert loops, m.group(1)
         for b in loops:
             assert "scratch_" not in b and "v_accvgpr" not in b, f"{m.group(1)}: spill or accumulator move inside the unit loop"
+    # half-tile and phase Winograd kernels (two / three workgroups per CU): no scratch in the unit loops; hipcc may park a few
+    # loop invariants in spare AGPRs at three waves per SIMD (84 + 84 registers), which costs one move each per unit
+    for m in re.finditer(r"^(_Z2\ddcx_conv_wino2[hp]_kernel\w+):[^\n]*\n", asm, re.M):
+        body = asm[m.end():asm.index(".Lfunc_end", m.end())]
+        loops = [b for b in re.split(r"\n\.LBB[0-9_]+:", body) if b.count("v_mfma") >= 64]
+        assert loops, m.group(1)
+        for b in loops:
+            assert "scratch_" not in b and b.count("v_accvgpr") <= 8, f"{m.group(1)}: spill inside the unit loop"
 
 
 def test_missing_native_library_fails_loudly(monkeypatch, tmp_path):

@@ -13,7 +13,7 @@ while [ $# -ge 2 ]; do
       /opt/rocm/bin/hipcc $FLAGS $extra -Rpass-analysis=kernel-resource-usage -c "$CS/dcx_conv_mfma.hip" -o "$ROOT/build_variants/$name.o" 2> "$ROOT/build_variants/$name.log"
       /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 "$ROOT/build_variants/$name.o" "$CS/dcx_misc.o" "$CS/dcx_tail.o" "$CS/dcx_api.o" -o "$ROOT/build_variants/lib_$name.so"
       rm -f "$ROOT/build_variants/$name.o"
-      echo "$name: $(grep -A8 'wino2h_kernelI12DcxWino2hCfgILi8ELi16ELb1' "$ROOT/build_variants/$name.log" | grep -oE 'VGPRs: [0-9]+|ScratchSize \[bytes/lane\]: [0-9]+' | paste -sd' ')"
+      echo "$name: w2h $(grep -A8 'wino2h_kernelI12DcxWino2hCfgILi8ELi16ELb1' "$ROOT/build_variants/$name.log" | grep -oE 'VGPRs: [0-9]+|ScratchSize \[bytes/lane\]: [0-9]+' | paste -sd' ') | w2p $(grep -A8 'wino2p_kernelI12DcxWino2pCfgILi8ELi16ELi2' "$ROOT/build_variants/$name.log" | grep -oE 'VGPRs: [0-9]+|ScratchSize \[bytes/lane\]: [0-9]+|Occupancy \[waves/SIMD\]: [0-9]+' | paste -sd' ')"
     ) &
 done
 wait
