@@ -59,6 +59,11 @@ struct CfgEntry {
       &dcx_conv_wino2p_launch_cfg<DcxWino2pCfg<TH, TW, EPI>>,                                              \
       "dcx_conv_wino2p_kernel<DcxWino2pCfg<" #TH "," #TW "," #EPI ">>" }
 
+#define DCX_W2PCFG_G(TH, TW, G)                                                                       \
+    { 64, 128, TH, TW, 3, 0, DCX_EPI_BNRELU, 5, 0, G, 4, 1,                                                  \
+      &dcx_conv_wino2p_launch_cfg<DcxWino2pCfg<TH, TW, DCX_EPI_BNRELU, G>>,                                \
+      "dcx_conv_wino2p_kernel<DcxWino2pCfg<" #TH "," #TW ",DCX_EPI_BNRELU," #G ">>" }
+
 #define DCX_W2CFG_G(TH, TW, G)                                                                        \
     { 64, 256, TH, TW, 3, 0, DCX_EPI_BNRELU, 16, 0, G, 2, 0,                                                \
       &dcx_conv_wino2_launch_cfg<DcxWino2Cfg<TH, TW, false, DCX_EPI_BNRELU, G>>,                           \
@@ -129,6 +134,7 @@ const CfgEntry kCfgs[] = {
     // phase variant + F(2x2,2x2) per phase: 2.25 multiply-adds per output pixel (the layer as written: 9)
     DCX_W2PCFG(8, 16, DCX_EPI_BNRELU),
     DCX_W2PCFG(8, 16, DCX_EPI_HEAT),
+    DCX_W2PCFG_G(8, 8, 2),    // two whole 8x8 low-resolution maps (RefineNet conv4a) per work item
 };
 
 int dcx_wino2h_mode() {   // DCX_WINO2H: 0 = never, 1 = cost model (default), 2 = whenever it can run the layer (A/B runs)
@@ -200,7 +206,8 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
     if (force != nullptr && force[0] != 0) {
         for (const CfgEntry& c : kCfgs)
             if (strcmp(c.name, force) == 0 && c.ks == ks && c.pool == pool && c.epi == epi && cout_pad % c.cout_tile == 0 &&
-                (c.group == 1 || (allow_group && ho <= c.th && wo <= c.tw)) && (!c.ups2 || ups == 1) &&
+                (c.group == 1 || (c.wino == 4 ? (ho <= 2 * c.th && wo <= 2 * c.tw) : (allow_group && ho <= c.th && wo <= c.tw))) &&
+                (!c.ups2 || ups == 1) &&
                 (c.wino != 3 || (cout_pad <= 128 && cin >= 2 * DCX_CCH)) &&
                 (c.wino != 4 || (cin >= 2 * DCX_CCH && (epi != DCX_EPI_HEAT || cout_pad == 64))))
                 return &c;
@@ -224,14 +231,15 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
             if (best == nullptr || cost_h < best_cost) { best_cost = cost_h; best = &c; }
             continue;
         }
-        if (c.group > 1 && (!allow_group || ho > c.th || wo > c.tw)) continue;   // grouped tiles: whole small maps only
+        if (c.group > 1 && c.wino != 4 && (!allow_group || ho > c.th || wo > c.tw)) continue;   // grouped tiles: whole small maps only
         if (c.ups2) {      // phase variant: only for layers reading a x2 up-sampled input; tiles are low-resolution, x4 items,
                            // 8 k-steps (4 taps x 2) per 16-channel unit
             if (ups != 1 || !dcx_ups2_enabled() || dcx_deterministic_enabled()) continue;
             if (c.wino == 4) {   // Winograd per phase: 9 x 8 MFMAs of 32 cycles per unit, two co-resident workgroups per CU
                 if (dcx_ups2w_mode() == 0 || !dcx_wino2_enabled() || cin < 2 * DCX_CCH || (epi == DCX_EPI_HEAT && cout_pad != 64)) continue;
+                if (c.group > 1 && (ho > 2 * c.th || wo > 2 * c.tw)) continue;        // grouped tiles: whole low-resolution maps only
                 const long wt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);
-                const double items_w = (double)n * (cout_pad / c.cout_tile) * wt * 4;
+                const double items_w = (double)((n + c.group - 1) / c.group) * (cout_pad / c.cout_tile) * wt * 4;
                 const double item_cost_w = (double)(cin / DCX_CCH) * (72 * 32.0 + 500.0) + 2400.0;
                 double cost_w = (double)(((long)items_w + n_cu - 1) / n_cu) * item_cost_w;
                 if (dcx_ups2w_mode() == 2) cost_w = 1.0;

@@ -49,23 +49,26 @@
 #define DCX_W2P_ATTR
 #endif
 
-template <int TH_, int TW_, int EPI_ = DCX_EPI_BNRELU>
+// G_ > 1: a work item covers G_ whole low-resolution maps of TH x TW pixels (RefineNet's 8x8 maps: two per item fill the 32 tiles)
+template <int TH_, int TW_, int EPI_ = DCX_EPI_BNRELU, int G_ = 1>
 struct DcxWino2pCfg {
     static constexpr int TH = TH_, TW = TW_;           // LOW-RESOLUTION pixels of one phase
     static constexpr int EPI = EPI_;
+    static constexpr int G = G_;
     static constexpr int NTHREADS = 256;
     static constexpr int COUT_TILE = 64;
     static constexpr int TY = TH / 2, TX = TW / 2;
-    static constexpr int NTILES = TY * TX;                 // <= 32
+    static constexpr int TPI = TY * TX;                    // 2x2 tiles per image
+    static constexpr int NTILES = G * TPI;                 // <= 32
     static constexpr int HH = TH + 1, RW = TW + 1;
     static constexpr int CQC = DCX_CCH / 4;
     static constexpr int NP = 9;
-    static constexpr int RAW = CQC * HH * RW;
+    static constexpr int RAW = G * CQC * HH * RW;         // [image][cq][row][col]
     static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;
     // raw tile in LDS: row pitch RP = RW + 1, row hy shifted by (hy >> 1) & 1 slots: the transform's ds_read_b64 of a 32-lane
     // group (16 tiles x 2 channel pairs: two tile rows) then covers 32 different 8-byte slots; slot RP - 1 of row 0 is free
     static constexpr int RP = RW + 1;
-    static constexpr int RAW_LDS = CQC * HH * RP;
+    static constexpr int RAW_LDS = G * CQC * HH * RP;
     static constexpr int VPLANE = CQC * 32;                // float4 per position: [cq][tile]
     static constexpr int LDS_FLOAT4 = NP * VPLANE;         // one transformed buffer (18 KB)
     static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_LDS) * 16;
@@ -75,7 +78,9 @@ struct DcxWino2pCfg {
     static constexpr int E_RAW_LOAD = 0;
     static constexpr int E_RAW_STORE = DCX_W2P_E_STORE;
     static constexpr int E_XFORM = DCX_W2P_E_XFORM;        // mid barrier before this event; 6 transform events follow
-    static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 32 && NTILES > 16 && TX == 8, "tile: 17..32 2x2 tiles, 8 per row");
+    static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 32 && NTILES > 16 && ((G == 1 && TX == 8) || (G == 2 && TX == 4 && TY == 4)),
+                  "tile: 17..32 2x2 tiles: 8 per row, or two 8x8 maps (the LDS row shift is built for these two shapes)");
+    static_assert(G == 1 || EPI == DCX_EPI_BNRELU, "grouped maps: plain BN + ReLU layers only");
     static_assert(ITER_R <= 3 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM % 2 == 0 && E_XFORM + 6 <= 2 * NP, "staging does not fit the schedule");
     static_assert(EPI == DCX_EPI_BNRELU || EPI == DCX_EPI_HEAT, "BN + ReLU, optionally followed by the RefineNet head");
 };
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
     const int n_ct = a.cout_pad / C::COUT_TILE;
     int n_eff = a.n;
     if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
-    const int total = n_eff * n_ct * tiles * 4;
+    const int total = ((n_eff + C::G - 1) / C::G) * n_ct * tiles * 4;      // G > 1: one work item covers G images (tiles == 1)
     int w = blockIdx.x, w_end = total, gstride = gridDim.x;
     if (a.xcd_walk && (gridDim.x & 7) == 0) {
         const int x = blockIdx.x & 7;
@@ -139,24 +144,28 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
 
     // ---- staging: raw tile [cq][hy][hx] of the LOW-RESOLUTION tensor, origin (ty TH - (1-a), tx TW - (1-b)) -------------
     auto rowoff = [](int row) { return (row >> 1) & 1; };
-    int r_hyx = 0, r_slot[ITER_R];          // r_hyx: (hy << 5 | hx) of the thread's raw pixels, 10 bits each
+    int r_hyx = 0, r_slot[ITER_R];          // r_hyx: (img << 9 | hy << 5 | hx) of the thread's raw pixels, 10 bits each
     unsigned r_rel[ITER_R];
+    const unsigned in_img_stride = (unsigned)a.in_cq_total * (unsigned)(a.hin * a.win);   // float4 between images
 #pragma unroll
     for (int k = 0; k < ITER_R; ++k) {
         const int idx = tid + k * C::NTHREADS;
-        const int cq = idx / (C::HH * RW);
-        const int hp = idx - cq * (C::HH * RW);
+        const int img = idx / (CQC * C::HH * RW);
+        const int rem = idx - img * (CQC * C::HH * RW);
+        const int cq = rem / (C::HH * RW);
+        const int hp = rem - cq * (C::HH * RW);
         const int hy = hp / RW, hx = hp - hy * RW;
-        r_hyx |= (hy << 5 | hx) << (10 * k);
-        r_rel[k] = idx < C::RAW ? (unsigned)((cq * a.hin + hy) * a.win + hx) * 16u : 0x80000000u;
-        r_slot[k] = idx < C::RAW ? (cq * C::HH + hy) * RP + hx + rowoff(hy) : RP - 1;
+        r_hyx |= (img << 9 | hy << 5 | hx) << (10 * k);
+        r_rel[k] = idx < C::RAW ? ((unsigned)img * in_img_stride + (unsigned)((cq * a.hin + hy) * a.win + hx)) * 16u : 0x80000000u;
+        r_slot[k] = idx < C::RAW ? ((img * CQC + cq) * C::HH + hy) * RP + hx + rowoff(hy) : RP - 1;
     }
     float4* sR = sB + 2 * LDSF;
     // transform piece of this thread: channel pair hb of (cq = wave, tile); tiles past the end redo the last tile
     const int x_hb = lane & 1;
-    const int x_tile = min(lane >> 1 | (lane & 32) >> 1, C::NTILES - 1);      // lanes 0..31: tiles 0..15, lanes 32..63: tiles 16..31
-    const int x_ty = x_tile / TX, x_tx = x_tile - x_ty * TX;
-    const int x_src = (wm * C::HH + 2 * x_ty) * RP + 2 * x_tx;
+    const int x_tile = min(lane >> 1, C::NTILES - 1);                           // lanes 0..31: tiles 0..15, lanes 32..63: tiles 16..31
+    const int x_img = x_tile / C::TPI, x_t = x_tile - x_img * C::TPI;
+    const int x_ty = x_t / TX, x_tx = x_t - x_ty * TX;
+    const int x_src = ((x_img * CQC + wm) * C::HH + 2 * x_ty) * RP + 2 * x_tx;
     const dcx_f32x2* sR2 = reinterpret_cast<const dcx_f32x2*>(sR);
     const int x_r0 = 2 * (x_src + rowoff(2 * x_ty)) + x_hb, x_r1 = 2 * (x_src + RP + rowoff(2 * x_ty + 1)) + x_hb,
               x_r2 = 2 * (x_src + 2 * RP + rowoff(2 * x_ty + 2)) + x_hb;      // float2 index of d[r][0]; d[r][s] at + 2 s
@@ -165,11 +174,12 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
     auto pad_x = [&](const DcxItem& it) { return 1 - (it.ph & 1); };
     auto unit_rsrc = [&](const DcxItem& it, int c) {
         const long tile_off = (long)(it.ty * C::TH - pad_y(it)) * a.win + (it.tx * C::TW - pad_x(it));
-        const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
+        const float* base = a.in + (((size_t)it.n * C::G * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
                                     + tile_off) * 4;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
     };
     auto tile_interior = [&](const DcxItem& it) {
+        if (C::G > 1) return false;        // whole maps: every tile touches the zero border (and the last group may be short)
         const int sy0 = it.ty * C::TH - pad_y(it), sx0 = it.tx * C::TW - pad_x(it);
         return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= a.hin && sx0 + RW <= a.win;
     };
@@ -237,8 +247,9 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
         const int sy0 = cur.ty * C::TH - pad_y(cur), sx0 = cur.tx * C::TW - pad_x(cur);
 #pragma unroll
         for (int k = 0; k < ITER_R; ++k) {
-            const int ly = sy0 + ((r_hyx >> (10 * k + 5)) & 31), lx = sx0 + ((r_hyx >> (10 * k)) & 31);
-            const bool inb = (unsigned)ly < (unsigned)a.hin && (unsigned)lx < (unsigned)a.win;
+            const int ly = sy0 + ((r_hyx >> (10 * k + 5)) & 15), lx = sx0 + ((r_hyx >> (10 * k)) & 31);
+            const bool inb = (unsigned)ly < (unsigned)a.hin && (unsigned)lx < (unsigned)a.win
+                          && (C::G == 1 || cur.n * C::G + ((r_hyx >> (10 * k + 9)) & 1) < n_eff);
             sR[r_slot[k]] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
         }
         __syncthreads();
@@ -283,8 +294,9 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
         if (!n_interior) {
 #pragma unroll
             for (int k = 0; k < ITER_R; ++k) {
-                const int ly = nsy0 + ((r_hyx >> (10 * k + 5)) & 31), lx = nsx0 + ((r_hyx >> (10 * k)) & 31);
-                const bool inb = (unsigned)ly < (unsigned)a.hin && (unsigned)lx < (unsigned)a.win;
+                const int ly = nsy0 + ((r_hyx >> (10 * k + 5)) & 15), lx = nsx0 + ((r_hyx >> (10 * k)) & 31);
+                const bool inb = (unsigned)ly < (unsigned)a.hin && (unsigned)lx < (unsigned)a.win
+                              && (C::G == 1 || nxt.n * C::G + ((r_hyx >> (10 * k + 9)) & 1) < n_eff);
                 roff[k] = inb ? r_rel[k] : 0x80000000u;
             }
         }
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
             const int g4e = lne >> 4, l15e = lne & 15;
             const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 4 + g4e;         // the lane's output channel quad
             char* obase = reinterpret_cast<char*>(a.out)
-                        + ((size_t)cur.n * a.out_cq_total + a.out_cq_off + cq) * (size_t)plane * 16;
+                        + ((size_t)cur.n * C::G * a.out_cq_total + a.out_cq_off + cq) * (size_t)plane * 16;
             float cf[NP];
             {
                 const float4* tp = reinterpret_cast<const float4*>(sT + (lne & 3) * 16);
@@ -373,9 +385,10 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
                 asm volatile("s_nop 7" : "+v"(e[tb][0]), "+v"(e[tb][1]), "+v"(e[tb][2]), "+v"(e[tb][3]));
                 __builtin_amdgcn_sched_barrier(0);
                 const int qt = tb * 16 + l15e;
-                const int qty = qt / TX, qtx = qt - qty * TX;
+                const int q_img = qt / C::TPI, q_t = qt - q_img * C::TPI;     // image inside the group (0 when G == 1)
+                const int qty = q_t / TX, qtx = q_t - qty * TX;
                 const int ly0 = cur.ty * C::TH + 2 * qty, lx0 = cur.tx * C::TW + 2 * qtx;     // low-resolution position of output k = 0
-                const bool qok = qt < C::NTILES && cq < a.cout_quads;
+                const bool qok = qt < C::NTILES && cq < a.cout_quads && (C::G == 1 || cur.n * C::G + q_img < n_eff);
                 const bool okr0 = qok && ly0 < a.hin, okr1 = qok && ly0 + 1 < a.hin;
                 const bool okc0 = lx0 < a.win, okc1 = lx0 + 1 < a.win;
                 if (C::EPI == DCX_EPI_HEAT) {
@@ -413,7 +426,8 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
                 }
                 {
                     // output k = (i, j) of the tile is low-resolution pixel (ly0 + i, lx0 + j) -> pixel (2 (ly0 + i) + a, 2 (lx0 + j) + b)
-                    char* dst = obase + (size_t)((unsigned)((2 * ly0 + pa) * a.wo + 2 * lx0 + pb) * 16u);
+                    char* dst = obase + (size_t)((unsigned)((2 * ly0 + pa) * a.wo + 2 * lx0 + pb) * 16u)
+                              + (C::G > 1 ? (size_t)q_img * a.out_cq_total * plane * 16 : 0);
                     if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = y[0];
                     if (okr0 && okc1) *reinterpret_cast<float4*>(dst + 32) = y[1];
                     if (okr1 && okc0) *reinterpret_cast<float4*>(dst + (size_t)a.wo * 32) = y[2];
@@ -512,7 +526,8 @@ static int dcx_conv_wino2p_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     if (a.ups != 1 || a.pad != 1 || a.ho != 2 * a.hin || a.wo != 2 * a.win) return DCX_E_SHAPE;
     if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0 || a.cin < 2 * DCX_CCH) return DCX_E_SHAPE;   // >= 2 units per work item
     if (C::EPI == DCX_EPI_HEAT && a.cout_pad != C::COUT_TILE) return DCX_E_SHAPE;     // the head sums over ONE cout tile
-    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y * 4;
+    if (C::G > 1 && (a.tiles_x != 1 || a.tiles_y != 1)) return DCX_E_SHAPE;                          // grouped: whole maps only
+    const long items = (long)((a.n + C::G - 1) / C::G) * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y * 4;
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
     const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * (C::EPI == DCX_EPI_HEAT ? 12 : 8) + 256;
     if (DCX_W2P_OCC * lds > 160 * 1024) return DCX_E_SHAPE;

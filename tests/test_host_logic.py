@@ -224,6 +224,7 @@ def test_tile_cost_model_choices():
     assert "DcxWino2Cfg<6,40,0>" in name(32, 128, 30, 40, 512, 3, 0, 0)                  # fused heads' 3x3 (512 couts): big tiles
     assert name_ups(512, 64, 64, 64, 64, 3, 0, 2, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,16,DCX_EPI_HEAT>>"    # RefineNet head behind the x2 up-sampling: phases + F(2x2,2x2)
     assert name_ups(512, 128, 32, 32, 64, 3, 0, 0, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,16,DCX_EPI_BNRELU>>"  # conv5a
+    assert name_ups(512, 128, 16, 16, 128, 3, 0, 0, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,8,DCX_EPI_BNRELU,2>>"   # conv4a: two 8x8 maps per item
     assert ",PH>>" in name_ups(16, 128, 32, 32, 64, 3, 0, 0, 1)                          # conv5a at bs=1 (16 patches): the small-tile phase kernel
     assert "DcxWino2Cfg<16,16,0,DCX_EPI_HEAT>" in name(512, 64, 64, 64, 64, 3, 0, 2)     # the same head without the phase variant
     assert "<1,4,2,2,1,256,1,0,DCX_EPI_RAW>" in name(32, 256, 1, 1200, 65, 1, 0, 1)

@@ -27,10 +27,11 @@ def per_kernel(path, counter):
 
 def lib_name(rocprof_name):
     m = re.search(r"DcxWino2pCfg<([^>]*)>", rocprof_name)
-    if m:   # <TH, TW, EPI>
+    if m:   # <TH, TW, EPI, G>
         f = [x.strip() for x in m.group(1).split(",")]
         epi = {"0": "DCX_EPI_BNRELU", "2": "DCX_EPI_HEAT"}[f[2] if len(f) > 2 else "0"]
-        return "dcx_conv_wino2p_kernel<DcxWino2pCfg<" + f[0] + "," + f[1] + "," + epi + ">>"
+        grp = ("," + f[3]) if len(f) > 3 and f[3] != "1" else ""
+        return "dcx_conv_wino2p_kernel<DcxWino2pCfg<" + f[0] + "," + f[1] + "," + epi + grp + ">>"
     m = re.search(r"DcxWino2hCfg<([^>]*)>", rocprof_name)
     if m:   # <TH, TW, POOL, EPI>
         f = [x.strip() for x in m.group(1).split(",")]
