@@ -923,6 +923,7 @@ def test_kernel_families_give_identical_corners(dev):
     results = {}
     for name, env in (("direct", {"DCX_WINO": "0", "DCX_WINO2": "0", "DCX_UPS2": "0"}), ("wino1d", {"DCX_WINO2": "0"}),
                       ("wino2d", {}), ("no_phase_flat_walk", {"DCX_UPS2": "0", "DCX_XCD_WALK": "0"}),
+                      ("plain_phase_no_half_tiles", {"DCX_UPS2W": "0", "DCX_WINO2H": "0"}),
                       ("deterministic", {"DCX_DETERMINISTIC": "1"})):
         e = dict(os.environ)
         e.pop("DCX_FORCE_CFG", None)
