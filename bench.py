@@ -190,7 +190,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
 
     n_i32 = packed_len(B, kmax)
     host_local = torch.empty((n_i32,), dtype=torch.int32).pin_memory()
-    og = OverlappedGather(n_i32, dev, backend=cx.backend) if world > 1 else None
+    dist_on = world > 1 or cx.force_dist      # --force-dist: the N>1 code path (process group, side-stream gather, barrier) with ONE rank
+    og = OverlappedGather(n_i32, dev, backend=cx.backend) if dist_on else None
     out_single = torch.empty((n_i32,), dtype=torch.int32, device=dev)
     state = {"i": 0}
 
@@ -211,7 +212,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         if og is not None:
             og.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +235,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if cx.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -316,7 +317,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     if os.environ.get("DCX_BENCH_CORRUPT_PARITY") and res_local and res_local[0].ndim == 2:   # test hook: prove that the gate gates
         res_local[0] = res_local[0].copy(); res_local[0][0, 0] += 1.0
     checks = [((name, 0, b), frames[b], res_local[b]) for b in pick]
-    if world > 1:
+    if dist_on:
         r = world - 1
         res_r = unpack_results(per_rank[r], B, kmax, True)[0]
         if fixed_k:
@@ -340,7 +341,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                    "e2e_frac_of_f32_mfma_peak": round(fps * gflop_frame / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
         "parity": parity,
     }
-    if world > 1:
+    if dist_on:
         out["gather_overlapped"] = bool(og.overlapped)
     if roofline is not None:
         out["roofline"] = roofline
@@ -430,6 +431,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs (the other BASELINE configs, bs=1 protocol)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, side-stream all-gather, barrier, MAX all-reduce) even with one rank: "
+                         "RCCL self-check on a 1-GPU box")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to smoke-test the multi-process flow "
                          "with several ranks on one GPU")
@@ -448,9 +452,12 @@ def main():
     torch.cuda.set_device(local_rank % ndev)
     cx.dev = dev = torch.device("cuda", local_rank % ndev)
     cx.dist = None
-    if world > 1:
+    cx.force_dist = bool(args.force_dist)
+    dist_on = world > 1 or cx.force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -484,7 +491,7 @@ def main():
             others["bs1_reference_protocol"] = bs1_reference_protocol(cx)
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             cx.dist.barrier()
             cx.dist.destroy_process_group()
         return
@@ -504,7 +511,7 @@ def main():
         line["other_configs"] = others
     print(json.dumps(line), flush=True)
     bad = main_res["parity"]["mismatched_frames"] + sum(v.get("parity", {}).get("mismatched_frames", 0) for v in others.values())
-    if world > 1:
+    if dist_on:
         cx.dist.barrier()
         cx.dist.destroy_process_group()
     if bad:

@@ -48,3 +48,10 @@ def test_two_ranks_on_one_gpu_gloo_real_kernels(tmp_path):
 def test_two_ranks_rccl_real_kernels(tmp_path):
     v = _launch("nccl", 2, tmp_path)
     assert v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["one_frame_ok"]
+
+
+def test_one_rank_rccl_real_kernels(tmp_path):
+    """RCCL itself on the 1-GPU box: a process group of ONE rank runs the same product path (all_gather_into_tensor on the
+    side stream, double-buffered, barrier) -- what the 8-GPU job does per rank, minus the peers."""
+    v = _launch("nccl", 1, tmp_path)
+    assert v["world"] == 1 and v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["one_frame_ok"] and v["corners"] > 50
