@@ -82,6 +82,20 @@ class OverlappedGather:
         self._pending = [False] * depth          # gloo: D2H issued, host all-gather not yet done
         self._used = [False] * depth
 
+    def warm_up(self, rounds: int = 64) -> None:
+        """Run the exchange ``rounds`` times on the (still unused) buffers and wait for it.  RCCL / c10d finish initialising
+        lazily during their first few dozen collectives (measured on MI355X: ~50 ms of host-side stalls spread over the first
+        ~35 calls, none afterwards); a caller that times steady-state steps pays that here instead."""
+        if self.backend != "nccl":
+            return
+        with torch.cuda.stream(self.side):
+            for r in range(rounds):
+                s = r % self.depth
+                work = dist.all_gather_into_tensor(self.gathered[s].view(-1), self.out[s], group=self.group, async_op=True)
+                work.wait()
+                self.host[s].copy_(self.gathered[s], non_blocking=True)
+        self.side.synchronize()
+
     def acquire(self, i: int) -> torch.Tensor:
         """Output buffer of step i; the compute stream waits until the side stream has released it."""
         s = i % self.depth
