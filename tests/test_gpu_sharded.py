@@ -55,3 +55,16 @@ def test_one_rank_rccl_real_kernels(tmp_path):
     side stream, double-buffered, barrier) -- what the 8-GPU job does per rank, minus the peers."""
     v = _launch("nccl", 1, tmp_path)
     assert v["world"] == 1 and v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["one_frame_ok"] and v["corners"] > 50
+
+
+def test_bench_n_gt_1_code_path_with_one_rccl_rank(tmp_path):
+    """bench.py --force-dist: the N>1 code path of the benchmark (nccl process group, communicator warm-up, side-stream gather,
+    barrier + MAX all-reduce around the timed region, parity of frames taken out of the gathered buffer) with one rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("DCX_FORCE_CFG", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--force-dist", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras", "--parity-frames", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["gather_overlapped"] is True and line["parity"]["mismatched_frames"] == 0 and line["parity"]["frames_checked"] >= 4
+    assert line["n_gpus"] == 1 and line["value"] > 1000
