@@ -307,6 +307,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                                          "source": f"{extra_steps} fully bracketed steps after the timed region"},
                     "per_kernel": {kname(k): {"ms_per_step": round(v[1] / extra_steps, 4),
                                               "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
+                                              "executed_frac": round(v[0] * scale_of(kname(k)) / (v[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if v[1] > 0 else None,
                                               "launches_per_step": v[2] / extra_steps,
                                               "clock_ghz": round(v[3] / v[1], 3) if v[1] > 0 else None}
                                    for k, v in full.items()}}
