@@ -181,19 +181,70 @@ def state_dict_from_checkpoint(path: str, kind: str, n_ids: int = 16, allow_unsa
     return sd
 
 
-def save_lightning_style_checkpoint(path: str, sd: StateDict) -> None:
+def save_lightning_style_checkpoint(path: str, sd: StateDict, full: bool = False, pl_version: str = "2.1.0") -> None:
     """Write ``sd`` the way Lightning would (``state_dict`` + ``model.`` prefix).
 
-    Used by tests and the benchmark to exercise :func:`load_models` end to end
-    with synthetic weights.
+    Used by tests and the benchmark to exercise :func:`load_models` end to end with synthetic weights.  ``full=True``
+    writes every top-level entry a ``Trainer.fit`` checkpoint of the reference's training scripts carries
+    (train.py:37-50: one ``ModelCheckpoint(monitor="val_loss", save_top_k=10)`` callback, Adam from
+    net.py:160-162 / refinenet.py:176-179) in the layout of ``pytorch_lightning`` ``pl_version`` (1.9.x and 2.1.x, the two
+    pins of the reference's requirement files): ``epoch``, ``global_step``, ``pytorch-lightning_version``,
+    ``state_dict``, ``loops``, ``callbacks`` (keyed by the callback's ``state_key`` string, holding paths and score
+    tensors), ``optimizer_states`` (Adam moments per parameter), ``lr_schedulers``, and for 2.x ``hparams_name`` /
+    ``hyper_parameters``.  Only tensors and plain containers, i.e. what ``torch.load(weights_only=True)`` accepts.
     """
+    import collections
     import torch
-    out = {"state_dict": {f"model.{k}": torch.from_numpy(np.ascontiguousarray(v))
-                          for k, v in sd.items()},
-           "epoch": 0, "global_step": 0}
-    for k in list(out["state_dict"]):
+    state = collections.OrderedDict()
+    for k, v in sd.items():
+        state[f"model.{k}"] = torch.from_numpy(np.ascontiguousarray(v))
         if k.endswith("running_var"):
-            out["state_dict"][k.replace("running_var", "num_batches_tracked")] = torch.tensor(0)
+            state[f"model.{k}".replace("running_var", "num_batches_tracked")] = torch.tensor(369700 if full else 0)
+    out = {"state_dict": state, "epoch": 0, "global_step": 0}
+    if full:
+        steps, epochs = 369700, 100
+        ck = f"/home/user/deepcharuco/src/tb_logs/ckpts/longrun-epoch={epochs - 1}-step={steps}.ckpt"
+
+        def progress(n):
+            return {"total": {"ready": n, "completed": n, "started": n, "processed": n},
+                    "current": {"ready": n % 3697, "completed": n % 3697, "started": n % 3697, "processed": n % 3697}}
+        loops = {
+            "fit_loop": {"state_dict": {}, "epoch_loop.state_dict": {"_batches_that_stepped": steps},
+                         "epoch_loop.batch_progress": dict(progress(steps), is_last_batch=True),
+                         "epoch_loop.scheduler_progress": progress(0),
+                         "epoch_loop.automatic_optimization.state_dict": {},
+                         "epoch_loop.automatic_optimization.optim_progress": {"optimizer": {"step": progress(steps), "zero_grad": progress(steps)}},
+                         "epoch_loop.manual_optimization.state_dict": {},
+                         "epoch_loop.val_loop.state_dict": {}, "epoch_loop.val_loop.batch_progress": dict(progress(40), is_last_batch=True),
+                         "epoch_progress": progress(epochs)},
+            "validate_loop": {"state_dict": {}, "batch_progress": dict(progress(0), is_last_batch=False)},
+            "test_loop": {"state_dict": {}, "batch_progress": dict(progress(0), is_last_batch=False)},
+            "predict_loop": {"state_dict": {}, "batch_progress": progress(0)},
+        }
+        cb_key = ("ModelCheckpoint{'monitor': 'val_loss', 'mode': 'min', 'every_n_train_steps': 0, 'every_n_epochs': 1, "
+                  "'train_time_interval': None}")
+        if pl_version.startswith("1."):
+            cb_key = cb_key[:-1] + ", 'save_on_train_epoch_end': None}"
+        params = [k for k in state if k.endswith((".weight", ".bias"))]       # Adam sees learnable tensors only
+        opt_state = {}
+        for i, k in enumerate(params):
+            opt_state[i] = {"step": torch.tensor(float(steps)), "exp_avg": torch.zeros_like(state[k]),
+                            "exp_avg_sq": torch.full_like(state[k], 1e-6)}
+        group = {"lr": 0.005, "betas": (0.9, 0.999), "eps": 1e-08, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(params)))}
+        out.update({
+            "epoch": epochs - 1, "global_step": steps, "pytorch-lightning_version": pl_version, "loops": loops,
+            "callbacks": {cb_key: {"monitor": "val_loss", "best_model_score": torch.tensor(0.0123), "best_model_path": ck,
+                                   "current_score": torch.tensor(0.0125), "dirpath": ck.rsplit("/", 1)[0],
+                                   "best_k_models": {ck: torch.tensor(0.0123), ck.replace("99", "98"): torch.tensor(0.0131)},
+                                   "kth_best_model_path": ck.replace("99", "98"), "kth_value": torch.tensor(0.0131),
+                                   "last_model_path": ""}},
+            "optimizer_states": [{"state": opt_state, "param_groups": [group]}],
+            "lr_schedulers": [],
+        })
+        if not pl_version.startswith("1."):
+            out.update({"hparams_name": "kwargs", "hyper_parameters": {"lr": 0.005, "n_ids": 16, "tags": ["longrun"]}})
     torch.save(out, path)
 
 

@@ -66,6 +66,16 @@ def import_reference():
         assert code == cv2.COLOR_BGR2GRAY
         return O.bgr2gray(img)
     cv2.cvtColor = cvtColor
+
+    # recording stand-in for cv2.solvePnP: the reference's solve_pnp (inference.py:15-29) is CALLED and what it hands to
+    # OpenCV (object points, image points, camera matrix, distortion) is captured -- the PnP solve itself is third-party
+    cv2.solvePnP_calls = []
+
+    def solvePnP(object_points, image_points, camera_matrix, dist_coeffs):
+        cv2.solvePnP_calls.append((np.array(object_points, copy=True), np.array(image_points, copy=True),
+                                   camera_matrix, dist_coeffs))
+        return True, np.zeros((3, 1)), np.zeros((3, 1))
+    cv2.solvePnP = solvePnP
     sys.modules["cv2"] = cv2
 
     sys.path.insert(0, REF)
@@ -289,10 +299,38 @@ def main():
     bgr = rng.integers(0, 256, (16, 24, 3), dtype=np.uint8)
     np.savez_compressed(os.path.join(outdir, "bgr2gray_formula.npz"), bgr=bgr, gray=O.bgr2gray(bgr))
 
-    # solve_pnp object-point construction (inference.py:15-26), before cv2.solvePnP
-    kp = np.array([[10.5, 20.25, 3], [100.0, 50.0, 0], [30.0, 31.0, 15], [7.0, 8.0, 9]])
-    objp, imgp = O.solve_pnp_object_points(kp, 5, 5, 0.01)
-    np.savez_compressed(os.path.join(outdir, "solve_pnp_points.npz"), kp=kp, objp=objp, imgp=imgp)
+    # solve_pnp (inference.py:15-29): the REFERENCE's function is called with a recording cv2.solvePnP; the fixture holds
+    # the arguments it handed to OpenCV for several boards (square 5x5, the demo's 5x5 at another scale, non-square 4x7 /
+    # 7x4, float and int key-point arrays, unsorted ids, repeated ids) plus the < 4 points short-circuit
+    import cv2 as cv2_stub
+    cam = np.array([[600.0, 0, 160], [0, 600.0, 120], [0, 0, 1]])
+    dist = np.zeros(5)
+    rng = np.random.default_rng(2024)
+    pnp_cases = [
+        (np.array([[10.5, 20.25, 3], [100.0, 50.0, 0], [30.0, 31.0, 15], [7.0, 8.0, 9]]), 5, 5, 0.01),
+        (np.array([[1.125, 2.0, 0], [3.0, 4.5, 5], [5.0, 6.0, 10], [7.0, 8.0, 15], [9.0, 1.0, 7], [2.0, 2.0, 7]]), 5, 5, 0.035),
+        (np.array([[12, 40, 17], [200, 31, 2], [77, 78, 9], [5, 6, 0], [319, 239, 11]], dtype=np.int64), 4, 7, 0.02),
+        (np.array([[12, 40, 17], [200, 31, 2], [77, 78, 9], [5, 6, 0], [319, 239, 11]], dtype=np.int64), 7, 4, 0.02),
+        (np.concatenate([rng.uniform(0, 320, (16, 2)), rng.permutation(16)[:, None].astype(np.float64)], axis=1), 5, 5, 0.01),
+    ]
+    fxp = dict(n_cases=np.array(len(pnp_cases)), cam=cam, dist=dist)
+    for i, (kp, cols, rows, sq) in enumerate(pnp_cases):
+        del cv2_stub.solvePnP_calls[:]
+        ret = ref_inf.solve_pnp(kp, cols, rows, sq, cam, dist)
+        assert ret[0] is True and len(cv2_stub.solvePnP_calls) == 1
+        objp, imgp, cam_seen, dist_seen = cv2_stub.solvePnP_calls[0]
+        assert cam_seen is cam and dist_seen is dist and objp.dtype == np.float32 and imgp.dtype == np.float32
+        o_objp, o_imgp = O.solve_pnp_object_points(kp, cols, rows, sq)                      # pins the oracle's restatement
+        assert o_objp.dtype == objp.dtype and np.array_equal(o_objp, objp) and np.array_equal(o_imgp, imgp)
+        fxp[f"kp{i}"], fxp[f"board{i}"] = kp, np.array([cols, rows, sq], np.float64)
+        fxp[f"objp{i}"], fxp[f"imgp{i}"] = objp, imgp
+    del cv2_stub.solvePnP_calls[:]
+    assert ref_inf.solve_pnp(pnp_cases[0][0][:3], 5, 5, 0.01, cam, dist) == (False, None, None)   # inference.py:16-17
+    assert not cv2_stub.solvePnP_calls
+    # legacy names (first case) kept for the host-thread PnP tests
+    fxp["kp"], fxp["objp"], fxp["imgp"] = fxp["kp0"], fxp["objp0"], fxp["imgp0"]
+    np.savez_compressed(os.path.join(outdir, "solve_pnp_points.npz"), **fxp)
+    print(f"[golden] solve_pnp: {len(pnp_cases)} calls of the reference's own solve_pnp recorded; oracle == reference")
 
     metrics_golden(outdir)
 

@@ -393,6 +393,20 @@ def test_load_models_from_lightning_style_checkpoint(dev, golden_tiny, tmp_path)
     assert rn2 is None
 
 
+@pytest.mark.parametrize("pl_version", ["1.9.3", "2.1.0"])
+def test_load_models_from_a_full_lightning_checkpoint(dev, golden_tiny, tmp_path, pl_version):
+    """load_models (inference.py:73-84) on files with the complete Trainer.fit key set (loops, callbacks keyed by
+    ModelCheckpoint{...}, Adam optimizer_states, lr_schedulers, pytorch-lightning_version, hyper_parameters): same
+    corners as the reference produced from the same weights."""
+    from deepcharuco_amd.inference import load_models, infer_image
+    p1, p2 = str(tmp_path / "dc_full.ckpt"), str(tmp_path / "rn_full.ckpt")
+    W.save_lightning_style_checkpoint(p1, golden_tiny.sd_dc, full=True, pl_version=pl_version)
+    W.save_lightning_style_checkpoint(p2, golden_tiny.sd_rn, full=True, pl_version=pl_version)
+    dc, rn = load_models(p1, p2, n_ids=16, device="cuda")
+    kp, _ = infer_image(golden_tiny.bgr, 16, dc, rn, device="cuda")
+    assert kp.dtype == np.float64 and np.array_equal(kp, golden_tiny.fx["final_rn"])
+
+
 # --------------------------------------------------------------------------- batch path vs live oracle
 
 def _calibrated(seed, frames, n_ids=16, target_per_frame=12):

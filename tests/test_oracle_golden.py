@@ -80,8 +80,14 @@ def test_no_corner_returns_empty(golden_tiny):
 
 
 def test_solve_pnp_points():
+    """The fixture holds what the REFERENCE's own solve_pnp (inference.py:15-29) handed to a recording cv2.solvePnP
+    (oracle/make_golden.py) -- several boards incl. non-square ones, int and float key-points, unsorted / repeated ids."""
     import os
     from conftest import GOLDEN
     d = np.load(os.path.join(GOLDEN, "solve_pnp_points.npz"))
-    objp, imgp = O.solve_pnp_object_points(d["kp"], 5, 5, 0.01)
-    assert np.array_equal(objp, d["objp"]) and np.array_equal(imgp, d["imgp"])
+    assert int(d["n_cases"]) >= 5
+    for i in range(int(d["n_cases"])):
+        cols, rows, sq = d[f"board{i}"]
+        objp, imgp = O.solve_pnp_object_points(d[f"kp{i}"], int(cols), int(rows), float(sq))
+        assert objp.dtype == np.float32 and imgp.dtype == np.float32
+        assert np.array_equal(objp, d[f"objp{i}"]) and np.array_equal(imgp, d[f"imgp{i}"]), i
