@@ -280,34 +280,36 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         achieved = flop / (msum * 1e-3) / 1e12
         conv_ms = sum(a[1] for a in full.values())
         conv_flop = sum(a[0] for a in full.values())
-        # The Winograd kernels execute only part of a layer's ALGORITHMIC multiply-adds on the matrix cores (1-D F(2,3):
-        # 2/3; 2-D F(2x2,3x3): 4/9), so `achieved` (algorithmic FLOP / time, what the contract asks for) can exceed the
-        # fp32-MFMA peak; `executed_*` is what the matrix pipe really ran.
-        # (",PH>>": the phase variant for up-sampled inputs executes 4 of the 9 taps' worth of MACs, with pre-summed weights)
-        scale_of = lambda nm: (0.25 if "wino2p" in nm else 4.0 / 9.0 if ("wino2" in nm or ",PH>>" in nm)
-                               else 2.0 / 3.0 if "wino" in nm else 1.0)      # executed / algorithmic MACs of the kernel family
+        # The Winograd families execute only part of a layer's ALGORITHMIC multiply-adds on the matrix cores (2-D F(2x2,3x3):
+        # 4/9; phases x F(2x2,2x2) behind an up-sampling: 1/4), so the algorithmic rate (FLOP of the layer as written / time)
+        # can exceed the fp32-MFMA peak; the roofline fraction is quoted on what the matrix pipe really ran.
+        scale_of = lambda nm: 0.25 if "wino2p" in nm else 4.0 / 9.0 if "wino2h" in nm else 1.0   # executed / algorithmic MACs
         exec_scale = scale_of(kname(dom_id))
         conv_exec = sum(a[0] * scale_of(kname(k)) for k, a in full.items())
-        algo = ("winograd F(2x2,3x3): 4/9 of the algorithmic MACs are executed" if "wino2" in kname(dom_id)
-                else "winograd F(2,3) along x: 2/3 of the algorithmic MACs are executed" if "wino" in kname(dom_id)
-                else "phase-decomposed 3x3 over a x2 up-sampled input: 4/9 of the algorithmic MACs are executed" if ",PH>>" in kname(dom_id)
+        algo = ("winograd F(2x2,3x3): 4/9 of the algorithmic MACs are executed" if "wino2h" in kname(dom_id)
+                else "x2 up-sampled input as four phases x winograd F(2x2,2x2): 1/4 of the algorithmic MACs are executed" if "wino2p" in kname(dom_id)
                 else "direct implicit GEMM")
+        # `achieved` / `frac` are what the matrix pipe EXECUTED (<= peak by construction); the algorithmic rate of the layer as
+        # written (what a direct convolution would have to sustain to be as fast) is reported beside it and may exceed the peak
         roofline = {"bound": "mfma", "kernel": kname(dom_id), "launches": launches, "algorithm": algo,
-                    "executed_achieved": round(achieved * exec_scale, 2),
-                    "executed_frac": round(achieved * exec_scale / PEAK_F32_MFMA_TFLOPS, 4),
+                    "achieved": round(achieved * exec_scale, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved * exec_scale / PEAK_F32_MFMA_TFLOPS, 4),
+                    "executed_over_algorithmic_flop": round(exec_scale, 4),
+                    "algorithmic_achieved": round(achieved, 2),
+                    "algorithmic_over_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(msum / launches, 4),
                     "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3),
-                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kname(dom_id)),
+                    "traffic": pmc_traffic(kname(dom_id)),
                     "shader_clock_ghz": round(clk / msum, 3),
-                    "all_conv_kernels": {"achieved": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2),
+                    "all_conv_kernels": {"achieved": round(conv_exec / (conv_ms * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(conv_ms / extra_steps, 3),
-                                         "frac": round(conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                         "executed_frac": round(conv_exec / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                         "frac": round(conv_exec / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                         "algorithmic_achieved": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2),
+                                         "algorithmic_over_peak": round(conv_flop / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                          "source": f"{extra_steps} fully bracketed steps after the timed region"},
                     "per_kernel": {kname(k): {"ms_per_step": round(v[1] / extra_steps, 4),
-                                              "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
-                                              "executed_frac": round(v[0] * scale_of(kname(k)) / (v[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if v[1] > 0 else None,
+                                              "algorithmic_tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
+                                              "frac": round(v[0] * scale_of(kname(k)) / (v[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if v[1] > 0 else None,
                                               "launches_per_step": v[2] / extra_steps,
                                               "clock_ghz": round(v[3] / v[1], 3) if v[1] > 0 else None}
                                    for k, v in full.items()}}
@@ -329,13 +331,15 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         res_local[0] = res_local[0].copy(); res_local[0][0, 0] += 1.0
     checks = [((name, 0, b), frames[b], res_local[b]) for b in pick]
     if dist_on:
-        r = world - 1
-        res_r = unpack_results(per_rank[r], B, kmax, True)[0]
-        if fixed_k:
-            fr_r, _ = WL.select_fixed_k_frames(frames_kind, FRAME_SEED + r * 100000, B, H, Wd, fixed_k, dc, dev)
-        else:
-            fr_r = W.synthetic_frames(frames_kind, FRAME_SEED + r * 100000, B, H, Wd)
-        checks += [((name, r, b), fr_r[b], res_r[b]) for b in pick[:max(2, n_check // 2)]]
+        # frames of EVERY other rank out of the gathered buffer (2 per rank; the last rank gets as many as rank 0 / 2)
+        for r in range(1, world):
+            res_r = unpack_results(per_rank[r], B, kmax, True)[0]
+            if fixed_k:
+                fr_r, _ = WL.select_fixed_k_frames(frames_kind, FRAME_SEED + r * 100000, B, H, Wd, fixed_k, dc, dev)
+            else:
+                fr_r = W.synthetic_frames(frames_kind, FRAME_SEED + r * 100000, B, H, Wd)
+            n_r = max(2, n_check // 2) if r == world - 1 else 2
+            checks += [((name, r, b), fr_r[b], res_r[b]) for b in ([0, B - 1] if n_r == 2 else pick[:n_r])]
     parity = parity_block(oracle, checks)
 
     out = {
@@ -429,7 +433,7 @@ def bs1_reference_protocol(cx, n_iter=500):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(WL.PRESETS), help="BASELINE config (per-GPU load); default cfg2 = configs[1]")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (overrides the preset)")
@@ -511,8 +515,12 @@ def main():
     line = {
         "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": round(fps / REFERENCE_README_FPS, 3), "dtype": "f32", "data": "synthetic",
-        "config": dict(main_res["config"], vs_baseline_note="reference README '>200 fps' (GTX1080Ti, bs=1, src/benchmark.py)"),
+        "scaling": "weak",
+        # no number is published for THIS metric (batched, HBM-resident frames): the reference's only figure is "> 200 fps" for
+        # its bs=1 infer_image loop on a GTX1080Ti -- the like-for-like ratio is other_configs.bs1_reference_protocol
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": dict(main_res["config"], vs_baseline_note="null: BASELINE.json publishes nothing for bs=32; the reference README's "
+                       "'>200 fps' (GTX1080Ti, bs=1, src/benchmark.py) is compared like for like in other_configs.bs1_reference_protocol"),
         "parity": main_res["parity"],
     }
     for k_ in ("gather_overlapped", "roofline", "cpu_baseline"):

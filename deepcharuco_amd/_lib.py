@@ -69,6 +69,8 @@ SIGNATURES = {
     "dcx_nchw_to_c4": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dcx_c4_to_nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dcx_set_timing": (_i, [_i]),
+    "dcx_get_timing": (_i, []),
+    "dcx_profile_enabled": (_i, []),
     "dcx_last_timings": (_i, [C.POINTER(C.c_float)]),
     "dcx_conv_pick_name": (C.c_char_p, [_i] * 8),
     "dcx_conv_pick_name_ups": (C.c_char_p, [_i] * 9),

@@ -27,24 +27,8 @@ std::vector<float> pack_conv(const float* w, int cout, int cin, int ks, int cout
     return out;
 }
 
-// 3x3 OIHW -> 1-D Winograd F(2,3) along x: [ky*4 + p][cin/4][cout_pad][4], u = G g per kernel row (dcx_conv_wino.h).
-// fp32, in this order (restated by oracle/conv_exact.c): u1 = ((g0+g1)+g2)*0.5f, u2 = ((g0-g1)+g2)*0.5f.
-std::vector<float> pack_conv_wino(const float* w, int cout, int cin, int cout_pad) {
-    const int cq = cin / 4;
-    std::vector<float> out((size_t)12 * cq * cout_pad * 4, 0.0f);
-    for (int o = 0; o < cout; ++o)
-        for (int i = 0; i < cin; ++i)
-            for (int ky = 0; ky < 3; ++ky) {
-                const float* g = w + ((size_t)o * cin + i) * 9 + ky * 3;
-                const float u[4] = {g[0], ((g[0] + g[1]) + g[2]) * 0.5f, ((g[0] - g[1]) + g[2]) * 0.5f, g[2]};
-                for (int p = 0; p < 4; ++p)
-                    out[(((size_t)(ky * 4 + p) * cq + (i >> 2)) * cout_pad + o) * 4 + (i & 3)] = u[p];
-            }
-    return out;
-}
-
 // 3x3 OIHW -> 2-D Winograd F(2x2,3x3): [xi*4 + nu][cin/4][cout_pad][4], U = G g G^T in fp32, rows (ky) first, then columns
-// (dcx_conv_wino2.h; restated by oracle/conv_exact.c).
+// (dcx_conv_wino2h.h; restated by oracle/conv_exact.c).
 std::vector<float> pack_conv_wino2(const float* w, int cout, int cin, int cout_pad) {
     const int cq = cin / 4;
     std::vector<float> out((size_t)16 * cq * cout_pad * 4, 0.0f);
@@ -66,7 +50,8 @@ std::vector<float> pack_conv_wino2(const float* w, int cout, int cin, int cout_p
     return out;
 }
 
-// 3x3 OIHW -> the four phase kernels of a 3x3 convolution over a nearest-x2 up-sampled input (dcx_conv_mfma.h, PH variant):
+// 3x3 OIHW -> the four phase kernels of a 3x3 convolution over a nearest-x2 up-sampled input (host-side intermediate of
+// pack_conv_ups2w; dcx_conv_wino2p.h explains the phases):
 // [phase = 2a + b][tap = 2 dy + dx][cin/4][cout_pad][4].  Row sets: a = 0: dy 0 <- {ky 0}, dy 1 <- {ky 1, 2}; a = 1: dy 0 <-
 // {ky 0, 1}, dy 1 <- {ky 2}; columns alike with b.  fp32, rows first then columns, left to right (restated by
 // oracle/conv_exact.c: dcx_oracle_conv_ups2_exact).
@@ -139,10 +124,8 @@ std::vector<float> pad_vec(const float* v, int c, int c_pad) {
 
 struct DevLayer {       // one MFMA convolution's parameters on the device
     float* w = nullptr;
-    float* w_wino = nullptr;   // 3x3 + BN layers only
     float* w_wino2 = nullptr;  // 3x3 + BN layers only
-    float* w_ups2 = nullptr;   // 3x3 + BN layers that read a x2 up-sampled input only
-    float* w_ups2w = nullptr;  // same layers, Winograd-transformed phase kernels
+    float* w_ups2w = nullptr;  // 3x3 + BN layers that read a x2 up-sampled input only: Winograd-transformed phase kernels
     float* bias = nullptr;
     float* alpha = nullptr;
     float* beta = nullptr;
@@ -157,9 +140,7 @@ int upload(const std::vector<float>& h, float** d) {
 
 void free_layer(DevLayer& l) {
     if (l.w) (void)hipFree(l.w);
-    if (l.w_wino) (void)hipFree(l.w_wino);
     if (l.w_wino2) (void)hipFree(l.w_wino2);
-    if (l.w_ups2) (void)hipFree(l.w_ups2);
     if (l.w_ups2w) (void)hipFree(l.w_ups2w);
     if (l.bias) (void)hipFree(l.bias);
     if (l.alpha) (void)hipFree(l.alpha);
@@ -186,9 +167,7 @@ int make_layer(const HostConv& h, int cin, int cout, int ks, DevLayer* out, bool
         for (int i = 0; i < cout; ++i) be[i] = fmaf(h.b[i], al[i], be[i]);
         rc = upload(al, &l.alpha);
         if (rc == 0) rc = upload(be, &l.beta);
-        if (rc == 0 && ks == 3) rc = upload(pack_conv_wino(h.w, cout, cin, l.cout_pad), &l.w_wino);
         if (rc == 0 && ks == 3) rc = upload(pack_conv_wino2(h.w, cout, cin, l.cout_pad), &l.w_wino2);
-        if (rc == 0 && ks == 3 && ups_input) rc = upload(pack_conv_ups2(h.w, cout, cin, l.cout_pad), &l.w_ups2);
         if (rc == 0 && ks == 3 && ups_input) rc = upload(pack_conv_ups2w(h.w, cout, cin, l.cout_pad), &l.w_ups2w);
     }
     if (rc != 0) { free_layer(l); return rc; }
@@ -286,7 +265,7 @@ DcxConvArgs conv_args(const DevLayer& l, const float* in, int n, int in_cq_total
                       int ups, int pad, float* out, int out_cq_total, const int* n_limit) {
     DcxConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.w = l.w; a.w_wino = l.w_wino; a.w_wino2 = l.w_wino2; a.w_ups2 = l.w_ups2; a.w_ups2w = l.w_ups2w; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
+    a.in = in; a.w = l.w; a.w_wino2 = l.w_wino2; a.w_ups2w = l.w_ups2w; a.bias = l.bias; a.alpha = l.alpha; a.beta = l.beta; a.out = out;
     a.n_limit = n_limit;
     a.n = n; a.in_cq_total = in_cq_total; a.in_cq_off = in_cq_off; a.cin = l.cin;
     a.hin = hin; a.win = win; a.ups = ups; a.pad = pad;
@@ -561,7 +540,7 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, int max_patches, 
         DcxConvArgs a = conv_args(rf->head_a, src, p, 16, 0, 32, 32, 1, 1, nullptr, 16, lim);
         a.head_w = rf->head_w; a.head_b = rf->head_b; a.heat = d_heat;
         a.part_val = (float*)(ws + L.pval); a.part_idx = (int*)(ws + L.pidx);
-        heat_tiles = dcx_conv_heat_tiles(a.ho, a.wo, a.w_ups2 != nullptr ? 1 : 0);
+        heat_tiles = dcx_conv_heat_tiles(a.ho, a.wo, a.w_ups2w != nullptr ? 1 : 0);
         if (heat_tiles <= 0 || heat_tiles > kRefTiles) return DCX_E_SHAPE;
         rc = dcx_launch_conv_mfma(a, 3, 0, DCX_EPI_HEAT, s);
         if (rc) return rc;
@@ -661,6 +640,7 @@ extern "C" int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf, c
 }
 
 extern "C" int dcx_set_timing(int enabled) { g_timing = enabled != 0; return 0; }
+extern "C" int dcx_get_timing(void) { return g_timing ? 1 : 0; }
 
 extern "C" int dcx_last_timings(float* h_ms4) {
     if (!h_ms4) return DCX_E_ARG;

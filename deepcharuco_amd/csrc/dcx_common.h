@@ -25,12 +25,9 @@ enum DcxEpilogue {
 struct DcxConvArgs {
     const float* in;       // C4 [N][in_cq_total][Hin][Win][4]
     const float* w;        // packed [ks*ks][cin/4][cout_pad][4]   (4 = cin % 4)
-    const float* w_wino;   // nullable; 3x3 + BN layers: F(2,3)-transformed weights [ky*4 + p][cin/4][cout_pad][4] (dcx_conv_wino.h)
-    const float* w_wino2;  // nullable; same layers: F(2x2,3x3)-transformed weights [xi*4 + nu][cin/4][cout_pad][4] (dcx_conv_wino2.h)
-    const float* w_ups2;   // nullable; 3x3 + BN layers read through a nearest x2 up-sampling: the four phases' pre-summed 2x2 kernels
-                           // [phase][tap][cin/4][cout_pad][4] (dcx_conv_mfma.h, PH variant)
-    const float* w_ups2w;  // nullable; same layers: the phases' 2x2 kernels F(2x2,2x2)-transformed
-                           // [phase][xi*3 + nu][cin/4][cout_pad][4] (dcx_conv_wino2p.h)
+    const float* w_wino2;  // nullable; 3x3 + BN layers: F(2x2,3x3)-transformed weights [xi*4 + nu][cin/4][cout_pad][4] (dcx_conv_wino2h.h)
+    const float* w_ups2w;  // nullable; 3x3 + BN layers read through a nearest x2 up-sampling: the four phases' pre-summed 2x2 kernels,
+                           // F(2x2,2x2)-transformed: [phase][xi*3 + nu][cin/4][cout_pad][4] (dcx_conv_wino2p.h)
     const float* bias;     // [cout_pad]
     const float* alpha;    // [cout_pad]  gamma / sqrt(var + eps)
     const float* beta;     // [cout_pad]  bn_beta - mean * alpha
@@ -58,7 +55,7 @@ struct DcxConvArgs {
     int cout_quads;        // valid output channel quads = ceil(cout / 4)
     int cout_real;         // un-padded output channels (profiling only)
     int tiles_x, tiles_y;
-    int xcd_walk;          // set by the launcher: XCD-aware item walk (dcx_conv_wino2.h)
+    int xcd_walk;          // set by the launcher: XCD-aware item walk
 };
 
 // Picks a tile configuration for (ho, wo, cout_pad, pool, epi, ks) and launches.

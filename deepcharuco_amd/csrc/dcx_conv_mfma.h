@@ -44,19 +44,10 @@ typedef unsigned int dcx_u32x4 __attribute__((ext_vector_type(4)));
 
 #define DCX_CCH 16  // input channels per LDS chunk ("unit" of the software pipeline)
 
-// PH_ ("phase" variant, KS_ = 2): a 3x3 convolution (pad 1) over a nearest-x2 UP-SAMPLED input, computed on the low-resolution
-// tensor.  Up-sampling repeats every input pixel 2x2, so the 3x3 window of output pixel (2y+a, 2x+b) only ever sees a 2x2
-// block of distinct low-resolution pixels: rows {y-1: ky=0 | y: ky=1,2} for a = 0, {y: ky=0,1 | y+1: ky=2} for a = 1, and
-// the same for columns.  Each of the four output phases (a, b) is therefore a 2x2 convolution with top/left padding
-// (1-a, 1-b) and pre-summed weights (dcx_api.hip: pack_conv_ups2) -- 4 multiply-adds per output instead of 9, with NO
-// transform of activations or outputs (the 2-D Winograd kernel reaches the same 4/9 with an input and an output
-// transform whose vector-ALU work the fp32 MFMA cannot overlap).  A work item is (image, cout tile, phase, LOW-RES tile);
-// its outputs are stored at stride 2.  Summation order: the direct kernel's (chunk / tap dy-major over the 2x2 / s / j).
-template <int WM_, int WN_, int MT_, int NT_, int TH_, int TW_, int KS_, bool POOL_, int EPI_, bool PH_ = false>
+template <int WM_, int WN_, int MT_, int NT_, int TH_, int TW_, int KS_, bool POOL_, int EPI_>
 struct DcxConvCfg {
     static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, TH = TH_, TW = TW_, KS = KS_;
     static constexpr bool POOL = POOL_;
-    static constexpr bool PH = PH_;
     static constexpr int EPI = EPI_;
     static constexpr int NTHREADS = WM * WN * 64;
     static constexpr int COUT_TILE = WM * MT * 32;
@@ -86,8 +77,7 @@ struct DcxConvCfg {
     static_assert(EPI != DCX_EPI_HEAT || (WM == 1 && !POOL), "heat epilogue needs all couts in one wave row");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
     static_assert(STEPS >= 2, "pipeline needs two k-steps per unit");
-    static_assert(!PH || (KS == 2 && !POOL && EPI != DCX_EPI_RAW), "phase variant: 2x2 taps, BN+ReLU (or head) epilogue, no pooling");
-    static_assert(PH || KS != 2, "2x2 taps exist only as the phase variant");
+    static_assert(KS == 3 || KS == 1, "3x3 or 1x1");
 };
 
 __device__ __forceinline__ float4 dcx_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -100,6 +90,17 @@ __device__ __forceinline__ float dcx_vmax(float x, float y) {
     return r;
 }
 typedef float dcx_f32x2 __attribute__((ext_vector_type(2)));
+// one v_pk_add_f32 (hipcc scalarises float2 +/- into two v_add_f32; every VALU instruction in a k-loop costs matrix time)
+__device__ __forceinline__ dcx_f32x2 dcx_pk_add(dcx_f32x2 x, dcx_f32x2 y) {
+    dcx_f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ dcx_f32x2 dcx_pk_sub(dcx_f32x2 x, dcx_f32x2 y) {
+    dcx_f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 // y = x * al + be on 4 channels as two v_pk_fma_f32 (packed fp32: 2 results per VALU instruction)
 __device__ __forceinline__ float4 dcx_fma4(float4 x, float4 al, float4 be) {
     const dcx_f32x2 lo = __builtin_elementwise_fma(dcx_f32x2{x.x, x.y}, dcx_f32x2{al.x, al.y}, dcx_f32x2{be.x, be.y});
@@ -121,7 +122,7 @@ __device__ __forceinline__ float4 dcx_relu_quad_max(float4 v) {
 
 struct DcxItem {   // one work item = (image, cout tile, [phase,] spatial tile); all fields wave-uniform
     int n, ct, ty, tx;
-    int ph;            // phase variant only: output phase 2a + b
+    int ph;            // dcx_conv_wino2p.h only: output phase 2a + b
 };
 
 // Persistent, software-pipelined kernel.
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     const int n_ct = a.cout_pad / C::COUT_TILE;
     int n_eff = a.n;
     if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
-    const int total = n_eff * n_ct * tiles * (C::PH ? 4 : 1);     // images are the slowest index: skipped ones are at the end
-    // XCD-aware item walk (see dcx_conv_wino2.h): block b runs on XCD b % 8 (observed; used for speed only), so the blocks
+    const int total = n_eff * n_ct * tiles;     // images are the slowest index: skipped ones are at the end
+    // XCD-aware item walk: block b runs on XCD b % 8 (observed; used for speed only), so the blocks
     // of one XCD walk one contiguous eighth of the item list and share halos / repeated inputs through their L2
     int w = blockIdx.x, w_end = total, gstride = gridDim.x;
     if (a.xcd_walk && (gridDim.x & 7) == 0) {
@@ -173,14 +174,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
         it.tx = wi % a.tiles_x; wi /= a.tiles_x;
         it.ty = wi % a.tiles_y; wi /= a.tiles_y;
         it.ph = 0;
-        if (C::PH) { it.ph = wi & 3; wi >>= 2; }       // the four phases of a tile are neighbours in the item list (same input)
         it.ct = wi % n_ct;
         it.n = wi / n_ct;
         return it;
     };
-    // top / left padding of an item: the layer's, or (phase variant) 1 - a / 1 - b
-    auto pad_y = [&](const DcxItem& it) { return C::PH ? 1 - (it.ph >> 1) : a.pad; };
-    auto pad_x = [&](const DcxItem& it) { return C::PH ? 1 - (it.ph & 1) : a.pad; };
+    auto pad_y = [&](const DcxItem&) { return a.pad; };
+    auto pad_x = [&](const DcxItem&) { return a.pad; };
 
     const int hl = a.hin << a.ups, wl = a.win << a.ups;  // logical (up-sampled) input size
 
@@ -223,9 +222,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     // buffer addressing: voffset = per-lane constant, soffset = uniform (unit base + step offset) in an SGPR,
     // the m-tile stride (512 B) goes into the instruction's immediate field -> no VALU per load
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(C::PH ? a.w_ups2 : a.w), (short)0, (int)((unsigned)(C::PH ? 4 : 1) * KS * KS * w_tap_stride), 0x00020000);
-    auto unit_wbase = [&](const DcxItem& it, int c) {      // phase variant: [phase][tap][cin/4][cout_pad][4]
-        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u + (C::PH ? (unsigned)it.ph * (KS * KS) * w_tap_stride : 0u);
+        const_cast<float*>(a.w), (short)0, (int)((unsigned)KS * KS * w_tap_stride), 0x00020000);
+    auto unit_wbase = [&](const DcxItem& it, int c) {
+        return (unsigned)((c * CQC) * a.cout_pad + it.ct * C::COUT_TILE) * 16u;
     };
     auto load_a = [&](unsigned wbase, int step, float4 (&dst)[MT]) {
         const int tap = step / (DCX_CCH / 8);
@@ -452,10 +451,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                 int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
                 bool ok = qok[nt] && sy < a.ho && sx < a.wo;
                 if (C::POOL) { ok = ok && (P4 || (l31 & 3) == 0); sy >>= 1; sx >>= 1; }
-                if (C::PH) {   // (sy, sx) is a low-resolution pixel: this item produces its phase-(a, b) output
-                    ok = qok[nt] && 2 * sy < a.ho && 2 * sx < a.wo;
-                    sy = 2 * sy + (cur.ph >> 1); sx = 2 * sx + (cur.ph & 1);
-                }
                 pix_ok[nt] = ok;
                 lane_off[nt] = ((unsigned)half * plane + (unsigned)(sy * ws + sx)) * 16u;
             }
@@ -527,10 +522,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                     const float logit = tot + a.head_b;
                     int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
                     bool ok = qok[nt] && sy < a.ho && sx < a.wo;
-                    if (C::PH) {
-                        ok = qok[nt] && 2 * sy < a.ho && 2 * sx < a.wo;
-                        sy = 2 * sy + (cur.ph >> 1); sx = 2 * sx + (cur.ph & 1);
-                    }
                     if (ok) {
                         const int idx = sy * a.wo + sx;
                         if (a.heat != nullptr && half == 0) a.heat[((size_t)n * a.ho + sy) * a.wo + sx] = logit;
@@ -554,7 +545,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
                         const int oi = red_i[wv];
                         if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
                     }
-                    const size_t slot = (size_t)n * (tiles * (C::PH ? 4 : 1)) + (size_t)cur.ph * tiles + cur.ty * a.tiles_x + cur.tx;
+                    const size_t slot = (size_t)n * tiles + cur.ty * a.tiles_x + cur.tx;
                     a.part_val[slot] = best;
                     a.part_idx[slot] = besti;
                 }
@@ -593,14 +584,8 @@ template <class C>
 static int dcx_conv_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     a.tiles_x = (a.wo + C::TW - 1) / C::TW;
     a.tiles_y = (a.ho + C::TH - 1) / C::TH;
-    if (C::PH) {      // tiles are cut in the LOW-RESOLUTION image the kernel reads; ho x wo stays the (x2) output size
-        if (a.ups != 1 || a.pad != 1 || a.w_ups2 == nullptr || a.ho != 2 * a.hin || a.wo != 2 * a.win) return DCX_E_SHAPE;
-        a.tiles_x = (a.win + C::TW - 1) / C::TW;
-        a.tiles_y = (a.hin + C::TH - 1) / C::TH;
-        a.ups = 0;    // addresses are low-resolution pixels
-    }
     if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0) return DCX_E_SHAPE;
-    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y * (C::PH ? 4 : 1);
+    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
     const int occ_env = dcx_occupancy_override();                      // tuning knob (DCX_OCC), 0 = default
     const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);   // persistent workgroups

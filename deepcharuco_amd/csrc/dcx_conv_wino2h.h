@@ -1,29 +1,47 @@
-// dcx_conv_wino2h.h -- the 2-D Winograd F(2x2, 3x3) convolution of dcx_conv_wino2.h on HALF-SIZE tiles with
-// v_mfma_f32_16x16x4_f32, so that a wave holds 128 accumulator registers instead of 256 and TWO workgroups share a CU.
+// dcx_conv_wino2h.h -- 3x3 convolution + BN + ReLU (+2x2 max-pool) as the 2-D Winograd transform F(2x2, 3x3) on the gfx950
+// fp32 matrix cores: 16 products per 2x2 output tile and input channel instead of 36, i.e. 4/9 of the direct convolution's
+// MFMAs.  THE kernel family of every 3x3 + BN + ReLU layer that does not read through an up-sampling (those: dcx_conv_wino2p.h);
+// the family is chosen from the layer shape alone (dcx_conv_mfma.hip: pick), so a frame's results do not depend on the batch it
+// travels in.  Read dcx_conv_mfma.h first; layouts and the persistent work walk are the same.
 //
-// Why: an fp32 MFMA owns the vector ALU and a co-resident wave only ever runs while the other one stalls (DESIGN.md 3.8,
-// tools/ubench/mfma_overlap.hip).  dcx_conv_wino2.h needs the whole 512-register file for one wave per SIMD, so every wait
-// of that wave (two barriers per unit, LDS / L2 latencies of the transform and the operands, scalar bookkeeping between
-// units, the store tail of the epilogue) idles the matrix pipe: ~13 % of a work item.  Here the second workgroup fills them.
+//   per 2x2 output tile (rows 2ty, 2ty+1; columns 2tx, 2tx+1) and input channel, d = the 4x4 input window whose top-left
+//   pixel is (2ty - pad, 2tx - pad):
+//     rows     t[xi][c] :  t0 = d[0][c]-d[2][c]   t1 = d[1][c]+d[2][c]   t2 = d[2][c]-d[1][c]   t3 = d[1][c]-d[3][c]
+//     columns  v[xi][nu]:  v0 = t[xi][0]-t[xi][2] v1 = t[xi][1]+t[xi][2] v2 = t[xi][2]-t[xi][1] v3 = t[xi][1]-t[xi][3]
+//     weights  u = G g G^T, transformed on the host in fp32 (rows first, then columns; h1 = ((h0+h1)+h2)*0.5f ...)
+//     m[xi][nu] += u[xi][nu] * v[xi][nu]
+//     y[i][j] = 0;  for p = xi*4 + nu ascending:  y[i][j] = fmaf(AT[i][xi]*AT[j][nu], m[xi][nu], y[i][j]),
+//               AT = [[1,1,1,0],[0,1,-1,-1]]  (a sequential fmaf chain over ALL 16 positions, zero coefficients included:
+//               it runs on the matrix cores as sixteen chained v_mfma_f32_4x4x1 per accumulator register)
 //
-//   workgroup = 4 waves = 64 couts x 32 2x2-tiles (8x16 output pixels); wave wm owns couts 16 wm .. 16 wm + 15 for ALL 32
-//   tiles (two 16-tile MFMA blocks) and all 16 Winograd positions: 16 x 2 x 4 = 128 accumulator registers (AGPRs).
+// GEMM view: 16 independent GEMMs (one per Winograd position), M = cout, N = 2x2 tiles, K = cin, on v_mfma_f32_16x16x4_f32.
+//   workgroup = 4 waves = 64 couts x 32 2x2-tiles; wave wm owns couts 16 wm .. 16 wm + 15 for ALL 32 tiles (two 16-tile MFMA
+//   blocks) and all 16 positions: 16 x 2 x 4 = 128 accumulator registers (AGPRs) -- so TWO workgroups share a CU: an fp32 MFMA
+//   owns the vector ALU and a co-resident wave only ever runs while the other one stalls, which is exactly
+//   what the barriers, LDS / L2 latencies, inter-unit bookkeeping and the epilogue's store tail need.
 //   v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) B(4x16); lane l supplies A[l % 16][l / 16], B[l / 16][l % 16] and holds
 //   D[4 (l / 16) + r][l % 16], r = 0..3.  With the C4 layouts a lane's float4 is channels 4g .. 4g+3 (g = l / 16) of its
 //   cout (A: weights [pos][cin/4][cout_pad][4]) or of its tile (B: sV[pos][cq][tile]); MFMA j consumes component j, i.e.
 //   channels {j, 4+j, 8+j, 12+j} of the 16-channel chunk.  One float4 per operand covers the whole chunk.
-//   Summation order of every m (restated bit-exactly by oracle/conv_exact.c, dcx_oracle_conv_wino2_exact(order = 1)):
+//   Summation order of every m (restated bit-exactly by oracle/conv_exact.c, dcx_oracle_conv_wino2h_exact):
 //       m = 0;  for chunk c (16 cin) / j in 0..3 / g in 0..3:  m = fmaf(u[16c + 4g + j], v[16c + 4g + j], m)
-//   Input transform, host-side weight transform, output transform (sixteen chained v_mfma_f32_4x4x1 per accumulator
-//   register), BN, ReLU, pooling: exactly dcx_conv_wino2.h.
+//   It does not depend on the tile shape, the grouping, the batch size or the CU count.
 //
-// Per unit (16 channels) a wave issues 16 positions x 8 MFMAs x 32 cycles = 4,096 matrix cycles; operands: one weight float4
-// (L2) and two activation float4 (LDS) per position.  Weight traffic per CU equals the big-tile kernel's (a wave covers all 32
-// tiles of its workgroup); LDS operand traffic doubles to ~32 B/clk/CU, well inside the 128 B/clk.  Staging = the big kernel's
-// scheme on a [4 cq][10][18] raw tile: 3 raw float4 per thread, mid barrier, then each thread transforms HALF a (cq, tile)
-// piece (two of the four xi rows: 12 ds_read_b128, 32 v_pk_add_f32, 8 ds_write_b128).  LDS 76 KB + per-channel constants.
+// Tiles: 8x16 or 6x20 output pixels of one image, or (G = 2) two WHOLE 8x8 maps with their own zero borders (RefineNet after its
+// pool).  Per unit (16 channels) a wave issues 16 positions x 8 MFMAs x 32 cycles = 4,096 matrix cycles; operands: one weight
+// float4 (L2) and two activation float4 (LDS) per position.  Staging: the next unit's raw tile [img][cq][rows][cols] is loaded
+// early in the unit (hardware out-of-range -> 0 for the padding), written to LDS in the middle, and after one extra barrier
+// each thread transforms HALF a (cq, tile) piece (two of the four xi rows: 12 ds_read_b128, 32 v_pk_add_f32, 8 ds_write_b128),
+// one event per MFMA group; the unit body is one basic block.  BN parameters of the lane's cout quad come straight from L2
+// in the epilogue (requested ahead of the output-transform chain), so the cout count is not limited by LDS.
+// hipcc notes (each a measured 2-10x slowdown, guarded by tests/test_host_logic.py::test_conv_kernels_do_not_spill): the MFMAs
+// are inline asm with "+a" accumulators; accumulators are only ever defined by asm; the first unit of every work item is a
+// PEELED copy of the unit body whose first MFMA on each accumulator takes C = 0; hazards hipcc does not pad around asm are
+// padded by hand (2 wait states ahead of a unit's first MFMAs, 20 between the last MFMA and the epilogue's first read).
 #pragma once
-#include "dcx_conv_wino2.h"
+#include "dcx_conv_mfma.h"
+
+#include <type_traits>
 
 // schedule constants (overridable for sweeps: make EXTRA="-DDCX_W2H_E_STORE=11 -DDCX_W2H_E_XFORM=16")
 #ifndef DCX_W2H_DQ
@@ -39,31 +57,34 @@
 #define DCX_W2H_E_XFORM 14
 #endif
 
-template <int TH_, int TW_, bool POOL_, int EPI_ = DCX_EPI_BNRELU>
+template <int TH_, int TW_, bool POOL_, int G_ = 1>
 struct DcxWino2hCfg {
     static constexpr int TH = TH_, TW = TW_;
+    static constexpr int G = G_;                           // images per work item: G = 2 packs two whole small maps (<= TH x TW each)
     static constexpr bool POOL = POOL_;
-    static constexpr int EPI = EPI_;
     static constexpr int NTHREADS = 256;
     static constexpr int COUT_TILE = 64;
     static constexpr int TY = TH / 2, TX = TW / 2;
-    static constexpr int NTILES = TY * TX;                 // <= 32
+    static constexpr int TPI = TY * TX;                    // 2x2 tiles per image region
+    static constexpr int NTILES = G * TPI;                 // <= 32
     static constexpr int HH = TH + 2, RW = TW + 2;
     static constexpr int CQC = DCX_CCH / 4;
-    static constexpr int RAW = CQC * HH * RW;
+    static constexpr int RAW = G * CQC * HH * RW;          // [image][cq][row][col]
     static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;
-    static constexpr int RAW_PAD = ITER_R * NTHREADS;
-    // raw tile in LDS: row pitch RP, row hy shifted by ROWOFF(hy).  The transform reads float4 (row 2 ty + i, col 2 tx + j) for
-    // 16-lane groups that mix four ty: with pitch RW all of them land on the even 16-B slots of the 256-B bank row (4-way
-    // conflicts, 35 % of the kernel's LDS cycles).  For TW = 16 a pitch of 20 and one slot of shift on every second row PAIR
-    // put the 16 lanes of each ds_read_b128 group on 16 different slots.  (6x20 tiles: no such shift exists for their
-    // 10-tile rows; they keep the plain layout.)
-    static constexpr bool SWZ = TW_ == 16;
-    static constexpr int RP = SWZ ? RW + 2 : RW;
-    static constexpr int RAW_LDS = SWZ ? CQC * HH * RP : RAW_PAD;      // SWZ: slot RP - 1 of row 0 is free -> dump slot
+    // Raw tile in LDS: row pitch RP, row hy shifted by ROWOFF(hy) slots.  The transform reads float4 (row 2 ty + i, col 2 tx + j)
+    // in 16-lane groups (16 consecutive tiles of one cq); with the plain layout those land on few of the sixteen 16-B slots of a
+    // 256-B bank row (4-way conflicts at TW = 16: 35 % of the kernel's LDS cycles).  Per tile shape:
+    //   TW = 16 (8 tiles per row, a group = two tile rows): pitch 20, one slot of shift on every second row PAIR -> 16 distinct slots;
+    //   TW = 20 (10 tiles per row): pitch 23 and the same shift: at most 2 lanes per slot (plain layout: 3) -- ten even slots of one
+    //           tile row cannot fit the eight even residues, so 2-way is the floor for this lane order;
+    //   8x8 maps, G = 2 (4 tiles per row, a group = one whole map): pitch 12, one slot of shift on every second PAIR of row pairs
+    //           -> the four tile rows start at residues 0, 8, 1, 9: 16 distinct slots.
+    static constexpr int RP = TW_ == 16 ? RW + 2 : TW_ == 20 ? RW + 1 : TW_ == 8 ? RW + 2 : RW + 1;
+    static constexpr int ROW_SHIFT = TW_ == 8 ? 2 : 1;     // ROWOFF(hy) = (hy >> ROW_SHIFT) & 1
+    static constexpr int RAW_LDS = G * CQC * HH * RP;      // slot RP - 1 of row 0 (shift 0, RW <= RP - 1) is free -> dump slot
     static constexpr int VPLANE = CQC * 32;                // float4 per position: [cq][tile]
     static constexpr int LDS_FLOAT4 = 16 * VPLANE;         // one transformed buffer (32 KB)
-    static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_LDS) * 16;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_LDS) * 16 + 256;     // + output-transform table
     static constexpr int DQ = DCX_W2H_DQ;                        // weights: positions ahead
     static constexpr int DQB = DCX_W2H_DQB;                        // transformed activations: positions ahead
     // staging schedule in events (two per position: 32 per unit, 128 matrix cycles apart)
@@ -72,7 +93,8 @@ struct DcxWino2hCfg {
     static constexpr int E_XFORM = DCX_W2H_E_XFORM;                   // mid barrier before this event; 12 transform events follow
     static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 32 && NTILES > 16, "tile must hold 17..32 2x2 tiles");
     static_assert(ITER_R <= 5 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM + 12 <= 32, "staging does not fit the schedule");
-    static_assert(EPI == DCX_EPI_BNRELU, "plain BN + ReLU (+ pool) layers only");
+    static_assert(G == 1 || (!POOL && TPI == 16), "grouped tiles: two plain 8x8 maps");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups must fit a CU's LDS");
 };
 
 template <class C>
@@ -86,12 +108,12 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = 16-cout group
     const int g4 = lane >> 4, l15 = lane & 15;                      // lane's channel quad of the chunk / row-or-column
 
-    // ---- work list (persistent, XCD-aware walk: see dcx_conv_wino2.h) ------------------------------------------
+    // ---- work list (persistent, XCD-aware walk: see the header comment) ------------------------------------------
     const int tiles = a.tiles_x * a.tiles_y;
     const int n_ct = a.cout_pad / C::COUT_TILE;
     int n_eff = a.n;
     if (a.n_limit != nullptr) n_eff = min(n_eff, *a.n_limit);
-    const int total = n_eff * n_ct * tiles;
+    const int total = ((n_eff + C::G - 1) / C::G) * n_ct * tiles;      // G > 1: one work item covers G images (tiles == 1)
     int w = blockIdx.x, w_end = total, gstride = gridDim.x;
     if (a.xcd_walk && (gridDim.x & 7) == 0) {
         const int x = blockIdx.x & 7;
@@ -139,27 +161,37 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
 
     // ---- staging: raw tile ---------------------------------------------------------------------------------------
     constexpr int RP = C::RP;
-    auto rowoff = [](int row) { return C::SWZ ? (row >> 1) & 1 : 0; };
-    int r_hyx[ITER_R], r_slot[ITER_R];       // (hy << 16 | hx) of the thread's raw pixels and their LDS slots
+    auto rowoff = [](int row) { return (row >> C::ROW_SHIFT) & 1; };
+    int r_hyx[ITER_R], r_slot[ITER_R];       // (hy << 16 | hx) of the thread's raw pixels (G > 1: the image of the group) and their LDS slots
     unsigned r_rel[ITER_R];
+    const unsigned in_img_stride = (unsigned)a.in_cq_total * (unsigned)(a.hin * a.win);   // float4 between images
 #pragma unroll
     for (int k = 0; k < ITER_R; ++k) {
         const int idx = tid + k * C::NTHREADS;
-        const int cq = idx / (C::HH * RW);
-        const int hp = idx - cq * (C::HH * RW);
+        const int img = idx / (CQC * C::HH * RW);
+        const int rem = idx - img * (CQC * C::HH * RW);
+        const int cq = rem / (C::HH * RW);
+        const int hp = rem - cq * (C::HH * RW);
         const int hy = hp / RW, hx = hp - hy * RW;
         r_hyx[k] = hy << 16 | hx;
         const int prow = ((hy - a.pad) >> a.ups) + a.pad, pcol = ((hx - a.pad) >> a.ups) + a.pad;
-        r_rel[k] = idx < C::RAW ? (unsigned)((cq * a.hin + prow) * a.win + pcol) * 16u : 0x80000000u;
-        r_slot[k] = idx < C::RAW ? (cq * C::HH + hy) * RP + hx + rowoff(hy) : C::SWZ ? RP - 1 : idx;
+        r_rel[k] = idx < C::RAW ? ((unsigned)img * in_img_stride + (unsigned)((cq * a.hin + prow) * a.win + pcol)) * 16u : 0x80000000u;
+        r_slot[k] = idx < C::RAW ? ((img * CQC + cq) * C::HH + hy) * RP + hx + rowoff(hy) : RP - 1;
+        if (C::G > 1) {
+            // a grouped tile always starts at pixel (0, 0) of its images: the zero-padding predicate is a per-piece constant
+            const int ly = hy - a.pad, lx = hx - a.pad;
+            if (!((unsigned)ly < (unsigned)(a.hin << a.ups) && (unsigned)lx < (unsigned)(a.win << a.ups))) r_rel[k] = 0x80000000u;
+            r_hyx[k] = img;     // what the per-unit check needs: which image of the group the piece reads
+        }
     }
     float4* sR = sB + 2 * LDSF;
     // transform piece of this thread: half h (xi rows 2h, 2h + 1) of (cq, tile); tiles past the end redo the last tile
     const int x_h = __builtin_amdgcn_readfirstlane(tid >> 7);          // wave-uniform: waves 0, 1 -> xi 0, 1; waves 2, 3 -> xi 2, 3
     const int x_cq = (tid >> 5) & 3;
     const int x_tile = min(tid & 31, C::NTILES - 1);
-    const int x_ty = x_tile / TX, x_tx = x_tile - x_ty * TX;
-    const int x_src = (x_cq * C::HH + 2 * x_ty) * RP + 2 * x_tx;       // raw slot of the window's top-left pixel (before the row shift)
+    const int x_img = x_tile / C::TPI, x_t = x_tile - x_img * C::TPI;
+    const int x_ty = x_t / TX, x_tx = x_t - x_ty * TX;
+    const int x_src = ((x_img * CQC + x_cq) * C::HH + 2 * x_ty) * RP + 2 * x_tx;   // raw slot of the window's top-left pixel (before the row shift)
     // rows of the half-piece, branch-free: first xi = row A - row B, second xi = row B + sgn * row C
     //   h = 0: xi 0 = d0 - d2 (A = 0, B = 2), xi 1 = d1 + d2 (C = 1, sgn = +1);  h = 1: xi 2 = d2 - d1 (A = 2, B = 1), xi 3 = d1 - d3 (C = 3, sgn = -1)
     const int x_ia = x_h ? 2 : 0, x_ib = x_h ? 1 : 2, x_ic = x_h ? 3 : 1;
@@ -170,11 +202,12 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     const int x_dst = (8 * x_h) * VPLANE + x_cq * 32 + x_tile;         // + local position * VPLANE
     auto unit_rsrc = [&](const DcxItem& it, int c) {
         const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
-        const float* base = a.in + (((size_t)it.n * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
+        const float* base = a.in + (((size_t)it.n * C::G * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
                                     + tile_off) * 4;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, 0x7fffffff, 0x00020000);
     };
     auto tile_interior = [&](const DcxItem& it) {
+        if (C::G > 1) return (it.n + 1) * C::G <= n_eff;   // all images of the group exist (spatial padding is folded into r_rel)
         const int sy0 = it.ty * C::TH - a.pad, sx0 = it.tx * C::TW - a.pad;
         return sy0 >= 0 && sx0 >= 0 && sy0 + C::HH <= hl && sx0 + RW <= wl;
     };
@@ -221,14 +254,8 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         }
     };
 
-    // ---- epilogue constants in LDS: alpha, beta2, output-transform table -----------------------------------------
-    float4* sP = sB + 2 * LDSF + C::RAW_LDS;
-    const int cq_pad = a.cout_pad >> 2;
-    for (int i = tid; i < cq_pad; i += C::NTHREADS) {
-        sP[i] = reinterpret_cast<const float4*>(a.alpha)[i];
-        sP[cq_pad + i] = reinterpret_cast<const float4*>(a.beta)[i];
-    }
-    float* sT = reinterpret_cast<float*>(sP + 2 * cq_pad);
+    // ---- output-transform table in LDS: T[k = 2i + j][p = 4 xi + nu] = AT[i][xi] * AT[j][nu] as [k][p] floats (256 B) ------
+    float* sT = reinterpret_cast<float*>(sB + 2 * LDSF + C::RAW_LDS);
     if (tid < 64) {
         const int k = tid >> 4, p = tid & 15, i = k >> 1, j = k & 1, xi = p >> 2, nu = p & 3;
         const int ci = i == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : xi == 1 ? 1 : -1);
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     }
     const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
 
-    // accumulators: acc[pos][tb], only ever defined by inline asm with an AGPR constraint (see dcx_conv_wino2.h)
+    // accumulators: acc[pos][tb], only ever defined by inline asm with an AGPR constraint (see the header comment)
     dcx_f32x4 acc[16][2];
 
     // ---- prologue: first unit staged synchronously ---------------------------------------------------------------
@@ -253,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
 #pragma unroll
         for (int k = 0; k < ITER_R; ++k) {
             const int ly = sy0 + (r_hyx[k] >> 16), lx = sx0 + (r_hyx[k] & 0xffff);
-            const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+            const bool inb = C::G > 1 ? (cur.n * C::G + r_hyx[k] < n_eff)
+                                      : ((unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl);
             sR[r_slot[k]] = stage_fetch(r0, inb ? r_rel[k] : 0x80000000u);
         }
         __syncthreads();
@@ -295,7 +323,8 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
 #pragma unroll
             for (int k = 0; k < ITER_R; ++k) {
                 const int ly = nsy0 + (r_hyx[k] >> 16), lx = nsx0 + (r_hyx[k] & 0xffff);
-                const bool inb = (unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl;
+                const bool inb = C::G > 1 ? (nxt.n * C::G + r_hyx[k] < n_eff)
+                                          : ((unsigned)ly < (unsigned)hl && (unsigned)lx < (unsigned)wl);
                 roff[k] = inb ? r_rel[k] : 0x80000000u;
             }
         }
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                         const float av = j == 0 ? aa.x : j == 1 ? aa.y : j == 2 ? aa.z : aa.w;
                         const float bv0 = j == 0 ? b0.x : j == 1 ? b0.y : j == 2 ? b0.z : b0.w;
                         const float bv1 = j == 0 ? b1.x : j == 1 ? b1.y : j == 2 ? b1.z : b1.w;
-                        // (hazards: see dcx_conv_wino2.h -- operands come from loads hipcc waits for; VALU-written candidates only
+                        // (hazards: see the header comment -- operands come from loads hipcc waits for; VALU-written candidates only
                         //  at the very start of a unit -> 2 wait states ahead of the first MFMA)
                         if (p == 0 && j == 0) asm volatile("s_nop 1");
                         if (ZERO && j == 0) {       // first touch of these two accumulators in this work item: C = 0
@@ -354,8 +383,11 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
             for (int p = 0; p < 16; ++p) { asm volatile("" : "+a"(acc[p][0])); asm volatile("" : "+a"(acc[p][1])); }
             const unsigned plane = (unsigned)(hs * ws);
             const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 4 + g4;          // the lane's output channel quad
+            // BN parameters of the quad straight from L2 (arrays are padded to cout_pad); the ~2,100 cycles of the output
+            // transform below cover the latency
+            const float4 al = reinterpret_cast<const float4*>(a.alpha)[cq], be = reinterpret_cast<const float4*>(a.beta)[cq];
             char* obase = reinterpret_cast<char*>(a.out)
-                        + ((size_t)cur.n * a.out_cq_total + a.out_cq_off + cq) * (size_t)plane * 16;
+                        + ((size_t)cur.n * C::G * a.out_cq_total + a.out_cq_off + cq) * (size_t)plane * 16;
             float cf[16];
             {
                 const float4* tp = reinterpret_cast<const float4*>(sT + (lane & 3) * 16);
@@ -379,14 +411,15 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
             }
             asm volatile("s_nop 7" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]),
                                      "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[1][2]), "+v"(e[1][3]));
-            const float4 al = sP[cq], be = sP[cq_pad + cq];
             const dcx_f32x2 al01 = {al.x, al.y}, al23 = {al.z, al.w}, be01 = {be.x, be.y}, be23 = {be.z, be.w};
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 const int qt = tb * 16 + l15;
-                const int qty = qt / TX, qtx = qt - qty * TX;
+                const int q_img = qt / C::TPI, q_t = qt - q_img * C::TPI;     // image inside the group (0 when G == 1)
+                const int qty = q_t / TX, qtx = q_t - qty * TX;
                 const int oy0 = cur.ty * C::TH + 2 * qty, ox0 = cur.tx * C::TW + 2 * qtx;
-                const bool qok = qt < C::NTILES && cq < a.cout_quads;
+                const bool qok = qt < C::NTILES && cq < a.cout_quads && (C::G == 1 || cur.n * C::G + q_img < n_eff);
+                char* const obase_i = obase + (C::G > 1 ? (size_t)q_img * a.out_cq_total * (size_t)plane * 16 : (size_t)0);
                 const bool okr0 = qok && oy0 < a.ho, okr1 = qok && oy0 + 1 < a.ho;
                 const bool okc0 = ox0 < a.wo, okc1 = ox0 + 1 < a.wo;
                 dcx_f32x2 bn[4][2];     // [i][k / 2]
@@ -409,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                     v.y = dcx_vmax(dcx_vmax(dcx_vmax(y[0].y, y[1].y), dcx_vmax(y[2].y, y[3].y)), 0.f);
                     v.z = dcx_vmax(dcx_vmax(dcx_vmax(y[0].z, y[1].z), dcx_vmax(y[2].z, y[3].z)), 0.f);
                     v.w = dcx_vmax(dcx_vmax(dcx_vmax(y[0].w, y[1].w), dcx_vmax(y[2].w, y[3].w)), 0.f);
-                    char* dst = obase + (size_t)((unsigned)((oy0 >> 1) * ws + (ox0 >> 1)) * 16u);
+                    char* dst = obase_i + (size_t)((unsigned)((oy0 >> 1) * ws + (ox0 >> 1)) * 16u);
                     if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = v;
                 } else {
 #pragma unroll
@@ -417,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                         y[k].x = dcx_vmax(y[k].x, 0.f); y[k].y = dcx_vmax(y[k].y, 0.f);
                         y[k].z = dcx_vmax(y[k].z, 0.f); y[k].w = dcx_vmax(y[k].w, 0.f);
                     }
-                    char* dst = obase + (size_t)((unsigned)(oy0 * ws + ox0) * 16u);
+                    char* dst = obase_i + (size_t)((unsigned)(oy0 * ws + ox0) * 16u);
                     if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = y[0];
                     if (okr0 && okc1) *reinterpret_cast<float4*>(dst + 16) = y[1];
                     if (okr1 && okc0) *reinterpret_cast<float4*>(dst + (size_t)ws * 16) = y[2];
@@ -457,10 +490,9 @@ static int dcx_conv_wino2h_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     a.tiles_y = (a.ho + C::TH - 1) / C::TH;
     if (a.w_wino2 == nullptr || a.alpha == nullptr || a.beta == nullptr || a.out == nullptr) return DCX_E_ARG;
     if (a.cout_pad % C::COUT_TILE != 0 || a.cin % DCX_CCH != 0 || a.cin < 2 * DCX_CCH) return DCX_E_SHAPE;   // >= 2 units per work item
-    const long items = (long)a.n * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
+    if (C::G > 1 && (a.tiles_x != 1 || a.tiles_y != 1 || a.ups != 0)) return DCX_E_SHAPE;                   // grouped tiles: whole maps
+    const long items = (long)((a.n + C::G - 1) / C::G) * (a.cout_pad / C::COUT_TILE) * a.tiles_x * a.tiles_y;
     if (items <= 0 || items > 0x7fffffffL) return DCX_E_SHAPE;
-    const size_t lds = C::LDS_BYTES + (size_t)a.cout_pad * 8 + 256;      // + alpha, beta2, output-transform table
-    if (2 * lds > 160 * 1024) return DCX_E_SHAPE;                        // the point of this kernel is two workgroups per CU
     const int occ_env = dcx_occupancy_override();                        // tuning knob (DCX_OCC = 1: one workgroup per CU)
     const long resident = (occ_env == 1 ? 1L : 2L) * dcx_device_cu_count();
     const long blocks = items < resident ? items : resident;
@@ -472,6 +504,6 @@ static int dcx_conv_wino2h_launch_cfg(DcxConvArgs a, hipStream_t stream) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set[dev_i] = true;
     }
-    hipLaunchKernelGGL((dcx_conv_wino2h_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), lds, stream, a);
+    hipLaunchKernelGGL((dcx_conv_wino2h_kernel<C>), dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
     return (int)hipGetLastError();
 }

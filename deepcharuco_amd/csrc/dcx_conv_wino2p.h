@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = 16-cout group (and the channel quad it transforms)
     const int g4 = lane >> 4, l15 = lane & 15;
 
-    // ---- work list (persistent, XCD-aware walk: see dcx_conv_wino2.h); the four phases of a tile are neighbours --------
+    // ---- work list (persistent, XCD-aware walk: see the header comment); the four phases of a tile are neighbours --------
     const int tiles = a.tiles_x * a.tiles_y;
     const int n_ct = a.cout_pad / C::COUT_TILE;
     int n_eff = a.n;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
         sT[tid] = p < 9 ? (float)(ci * cj) : 0.f;
     }
 
-    dcx_f32x4 acc[NP][2];       // acc[pos][tb], only ever defined by inline asm with an AGPR constraint (see dcx_conv_wino2.h)
+    dcx_f32x4 acc[NP][2];       // acc[pos][tb], only ever defined by inline asm with an AGPR constraint (see the header comment)
 
     // ---- prologue: first unit staged synchronously ---------------------------------------------------------------
     DcxItem cur = decode(w);

@@ -7,10 +7,16 @@ H2D of the frame from pinned memory, BGR->gray on the device (``dcx_bgr2gray``),
 (``dcx_infer_batch``), D2H of the packed corner list -- into ONE hipGraph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm)
 and replays it per call: one launch from the host instead of ~30.  Results are those of ``infer_batch`` (same kernels,
 same order); a frame that fires more than ``kmax`` cells falls back to the eager path, which re-runs with a larger
-capacity.  Not thread-safe (one instance per thread / stream, like the C handles).
+capacity.  A pipeline owns its pinned / device buffers and its stream, so ``run`` is serialised by a per-pipeline lock and
+``cached_pipeline`` hands every thread its own instance: concurrent ``infer_image`` callers on one model pair never share
+staging buffers.  The graph freezes the kernel choice made at capture time, so the cache key also carries the library's
+process-global mode (``dcx_get_deterministic``) and graphs are bypassed while per-stage timing / per-launch profiling is on
+(their hipEvents would be frozen into or out of the graph).
 """
 from __future__ import annotations
 
+import threading
+import weakref
 from typing import List, Optional
 
 import numpy as np
@@ -49,10 +55,12 @@ class GraphedPipeline:
                     self._enqueue()
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            # thread_local: other threads may replay their own graphs / allocate while this one captures
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 self._enqueue()
         self._in_np = self.pin_in.numpy()
         self._out_np = self.pin_out.numpy()
+        self._lock = threading.Lock()
 
     def _enqueue(self) -> None:
         self.dev_in.copy_(self.pin_in, non_blocking=True)
@@ -66,31 +74,76 @@ class GraphedPipeline:
         """frames: (B,H,W,3) BGR or (B,H,W) gray uint8 host array (as configured) -> list of B keypoint arrays."""
         if frames.shape != self._in_np.shape or frames.dtype != np.uint8:
             raise ValueError(f"expected uint8 frames of shape {self._in_np.shape}, got {frames.dtype} {frames.shape}")
-        np.copyto(self._in_np, frames)
-        with torch.cuda.device(self.dev):
-            self.graph.replay()
-            torch.cuda.current_stream().synchronize()
-        res, counts = unpack_results(self._out_np, self.batch, self.kmax, self.refinenet is not None)
-        if int(counts.max()) > self.kmax:                 # rare: capacity exceeded -> exact eager re-run
-            gray = frames if not self.bgr else self.gray.cpu().numpy()
-            res = infer_batch(gray, self.dust_bin_ids, self.deepc, self.refinenet, kmax=self.kmax)
+        with self._lock:                                      # the staging buffers belong to this pipeline: one run at a time
+            np.copyto(self._in_np, frames)
+            with torch.cuda.device(self.dev):
+                self.graph.replay()
+                torch.cuda.current_stream().synchronize()
+            res, counts = unpack_results(self._out_np, self.batch, self.kmax, self.refinenet is not None)
+            if int(counts.max()) > self.kmax:                 # rare: capacity exceeded -> exact eager re-run
+                gray = frames if not self.bgr else self.gray.cpu().numpy()
+                res = infer_batch(gray, self.dust_bin_ids, self.deepc, self.refinenet, kmax=self.kmax)
         return res
 
 
-_cache: dict = {}
-_CACHE_MAX = 8
+_CACHE_MAX = 8        # per detector: graphs pin ~25 MB of workspace per 320x240 shape
+_cache_lock = threading.Lock()
+_capture_lock = threading.Lock()
+_caches: "weakref.WeakSet" = weakref.WeakSet()     # the per-detector caches that exist (for clear_graph_cache())
+
+
+class _Cache(dict):
+    __slots__ = ("__weakref__",)
+
+
+def graphs_usable() -> bool:
+    """False while per-stage timing or per-launch profiling is on: their hipEvent records must run eagerly."""
+    L = _lib.lib()
+    return not (L.dcx_get_timing() or L.dcx_profile_enabled())
+
+
+def clear_graph_cache(deepc=None) -> None:
+    """Drop the captured graphs (and their pinned / workspace buffers) of one detector, or of all of them."""
+    with _cache_lock:
+        if deepc is not None:
+            det = deepc.model if hasattr(deepc, "model") else deepc
+            c = getattr(det, "_graph_cache", None)
+            if c is not None:
+                c.clear()
+            return
+        for c in list(_caches):
+            c.clear()
+
+
+def drop_graphs_of_refiner(ref) -> None:
+    """Called when a RefineNet releases its C handle (reload / ``to(device)`` / destruction): graphs captured with it hold
+    pointers into the freed weights."""
+    with _cache_lock:
+        for c in list(_caches):
+            for k in [k for k in c if k[0] is not None and k[0][0] == id(ref)]:
+                c.pop(k, None)
 
 
 def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int, bgr: bool,
                     kmax: int = DEFAULT_KMAX) -> Optional[GraphedPipeline]:
-    """One graph per (model pair, shape) for ``infer_image``; a small LRU (graphs pin ~25 MB of workspace per 320x240 shape)."""
+    """One graph per (model pair, shape, library mode, calling thread) for ``infer_image``.  The cache lives ON the detector
+    object (a small LRU), so graphs die with the model instead of pinning it in a module-global table, and a re-allocated
+    model can never alias a cached graph of a freed one."""
     det = deepc.model if hasattr(deepc, "model") else deepc
     ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
-    key = (id(det), det.handle.value, id(ref), None if ref is None else ref.handle.value, dust_bin_ids, height, width, bgr, kmax)
-    p = _cache.pop(key, None)
+    key = (None if ref is None else (id(ref), ref.handle.value), dust_bin_ids, height, width, bgr, kmax,
+           int(_lib.lib().dcx_get_deterministic()), threading.get_ident())
+    with _cache_lock:
+        cache = getattr(det, "_graph_cache", None)
+        if cache is None:
+            cache = det._graph_cache = _Cache()
+            _caches.add(cache)
+        p = cache.pop(key, None)
     if p is None:
-        p = GraphedPipeline(dust_bin_ids, deepc, refinenet, 1, height, width, kmax, bgr)
-        while len(_cache) >= _CACHE_MAX:
-            _cache.pop(next(iter(_cache)))
-    _cache[key] = p
+        with _capture_lock:                                   # one capture at a time per process
+            p = GraphedPipeline(dust_bin_ids, deepc, refinenet, 1, height, width, kmax, bgr)
+    with _cache_lock:
+        while len(cache) >= _CACHE_MAX:
+            cache.pop(next(iter(cache)))
+        cache[key] = p
     return p

@@ -66,17 +66,18 @@ def solve_pnp(keypoints, col_count, row_count, square_len, camera_matrix, dist_c
     return _cv2_solvepnp()(object_points_found, image_points, camera_matrix, dist_coeffs)
 
 
-_pnp_pool = None
+_pnp_pools: dict = {}
 
 
 def _pool(workers: Optional[int]):
-    """One process-wide thread pool for the PnP stage (cv2 releases the GIL inside solvePnP)."""
-    global _pnp_pool
+    """Process-wide thread pools for the PnP stage (cv2 releases the GIL inside solvePnP), one per worker count."""
     import concurrent.futures as cf
     import os
-    if _pnp_pool is None or (workers is not None and workers != _pnp_pool._max_workers):
-        _pnp_pool = cf.ThreadPoolExecutor(max_workers=workers or min(32, os.cpu_count() or 1), thread_name_prefix="dcx-pnp")
-    return _pnp_pool
+    n = int(workers) if workers else min(32, os.cpu_count() or 1)
+    pool = _pnp_pools.get(n)
+    if pool is None:
+        pool = _pnp_pools[n] = cf.ThreadPoolExecutor(max_workers=n, thread_name_prefix="dcx-pnp")
+    return pool
 
 
 def solve_pnp_submit(keypoints_list, col_count, row_count, square_len, camera_matrix, dist_coeffs, workers: Optional[int] = None):
@@ -113,6 +114,8 @@ def set_deterministic(enabled: bool = True) -> None:
     """Force the direct convolution kernels for every layer: logits become bit-identical across batch sizes and devices
     (``dcx_set_deterministic``).  Process-global."""
     _lib.check(_lib.lib().dcx_set_deterministic(1 if enabled else 0), "dcx_set_deterministic")
+    from .graph import clear_graph_cache
+    clear_graph_cache()          # captured graphs froze the kernels chosen under the previous mode
 
 
 def _unwrap(deepc, refinenet):
@@ -253,7 +256,8 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
     if not isinstance(img, np.ndarray) or img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
         raise ValueError("expected a (H,W,3) uint8 BGR image")
     keypoints = None
-    if _graphs_enabled():
+    from .graph import graphs_usable
+    if _graphs_enabled() and graphs_usable():
         try:
             from .graph import cached_pipeline
             if _opencv():

@@ -53,6 +53,10 @@ class RefineNet:
 
     def _release(self):
         if self._handle is not None:
+            import sys
+            g = sys.modules.get("deepcharuco_amd.graph")     # only if a hipGraph may have been captured with this handle
+            if g is not None:
+                g.drop_graphs_of_refiner(self)
             _lib.lib().dcx_refiner_destroy(self._handle)
             self._handle = None
 

@@ -102,6 +102,13 @@ class FrameStream:
         """batches: iterable of (n,H,W) uint8 arrays -> (ticket, per-frame keypoint arrays[, per-frame (ret, rvec, tvec)])
         in submission order.  The PnP futures of a retired batch are resolved one submission later, so they run on the
         host threads while the next batch is being staged and the GPU is busy."""
+        if self.pnp is None:                  # nothing to overlap: hand every retired batch out at once
+            for fr in batches:
+                r = self.submit(fr)
+                if r is not None:
+                    yield r
+            yield from self.flush()
+            return
         held = None
         for fr in batches:
             r = self.submit(fr)

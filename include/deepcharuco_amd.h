@@ -170,6 +170,7 @@ int dcx_c4_to_nchw(const float* d_c4, int n, int c, int h, int w, float* d_nchw,
  * stream has been synchronised by the caller, dcx_last_timings() returns milliseconds:
  * [0] detector conv stack, [1] decode+table+gather, [2] RefineNet, [3] total.              */
 int dcx_set_timing(int enabled);
+int dcx_get_timing(void);            /* 1 while per-stage timing is on (callers that capture hipGraphs must launch eagerly then) */
 int dcx_last_timings(float* h_ms4);
 
 /* name of the kernel instantiation the tile cost model selects for a launch shape (host only, no GPU needed);
@@ -196,6 +197,7 @@ int dcx_get_deterministic(void);
  * (images the grid covered), limited[i] (1 if a device-side patch count may have skipped some
  * of them), flops_per_image[i] = 2*cout*cin*ks*ks*Ho*Wo (algorithmic, un-padded), ms[i].      */
 int dcx_profile_enable(int enabled);
+int dcx_profile_enabled(void);       /* 1 while per-launch profiling is on */
 int dcx_profile_count(void);
 /* restrict recording to one kernel id (-1 = all): keeps the event overhead out of a timed region */
 int dcx_profile_filter(int kernel_id);

@@ -71,63 +71,18 @@ void dcx_oracle_conv_exact(const float* x, int n, int cin, int h, int w, const f
                 }
 }
 
-/* Same layer through the 1-D Winograd F(2,3) kernel (deepcharuco_amd/csrc/dcx_conv_wino.h), in ITS exact fp32 order:
- *   per output pair (x0 = 2i, x0+1), kernel row ky, channel:  d_e = in[oy-pad+ky][x0-pad+e], e = 0..3 (0 outside)
- *     v0 = d0-d2  v1 = d1+d2  v2 = d2-d1  v3 = d1-d3;   u0 = g0  u1 = ((g0+g1)+g2)*0.5f  u2 = ((g0-g1)+g2)*0.5f  u3 = g2
- *   m_p = 0;  for chunk c0 / ky / s / j / k:  m_p = fmaf(u_p[ci], v_p[ci], m_p),  ci = c0 + 8s + 4k + j
- *   out[x0] = (m0+m1)+m2,  out[x0+1] = (m1-m2)-m3,  y = max(fmaf(out, alpha, fmaf(bias, alpha, beta)), 0)
- * 3x3 + BN + ReLU layers only (cin % 16 == 0). */
-void dcx_oracle_conv_wino_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
-                                const float* alpha, const float* beta, int cout, int pad, float* y) {
-    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
-    const int npair = (wo + 1) / 2;
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int b = 0; b < n; ++b)
-        for (int co = 0; co < cout; ++co)
-            for (int oy = 0; oy < ho; ++oy)
-                for (int pr = 0; pr < npair; ++pr) {
-                    const int x0 = 2 * pr;
-                    float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    for (int c0 = 0; c0 < cin; c0 += 16)
-                        for (int ky = 0; ky < 3; ++ky) {
-                            const int iy = oy - pad + ky;
-                            for (int s = 0; s < 2; ++s)
-                                for (int j = 0; j < 4; ++j)
-                                    for (int k = 0; k < 2; ++k) {
-                                        const int ci = c0 + 8 * s + 4 * k + j;
-                                        float d[4];
-                                        for (int e = 0; e < 4; ++e) {
-                                            const int ix = x0 - pad + e;
-                                            const int inb = iy >= 0 && iy < h && ix >= 0 && ix < w;
-                                            d[e] = inb ? x[(((size_t)b * cin + ci) * h + iy) * w + ix] : 0.0f;
-                                        }
-                                        const float* g = wt + ((size_t)co * cin + ci) * 9 + ky * 3;
-                                        const float u[4] = {g[0], ((g[0] + g[1]) + g[2]) * 0.5f, ((g[0] - g[1]) + g[2]) * 0.5f, g[2]};
-                                        const float v[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
-                                        for (int p = 0; p < 4; ++p) m[p] = fmaf(u[p], v[p], m[p]);
-                                    }
-                        }
-                    const float o0 = (m[0] + m[1]) + m[2], o1 = (m[1] - m[2]) - m[3];
-                    const float b2 = fmaf(bias[co], alpha[co], beta[co]);
-                    float* row = y + (((size_t)b * cout + co) * ho + oy) * wo;
-                    row[x0] = fmaxf(fmaf(o0, alpha[co], b2), 0.0f);
-                    if (x0 + 1 < wo) row[x0 + 1] = fmaxf(fmaf(o1, alpha[co], b2), 0.0f);
-                }
-}
-
-/* Same layer through the 2-D Winograd F(2x2,3x3) kernel (deepcharuco_amd/csrc/dcx_conv_wino2.h), in ITS exact fp32 order:
+/* Same layer through the 2-D Winograd F(2x2,3x3) kernel family (deepcharuco_amd/csrc/dcx_conv_wino2h.h), in ITS exact fp32 order:
  *   per 2x2 output tile (rows 2ty, 2ty+1; columns 2tx, 2tx+1), channel: d[r][c] = in[2ty-pad+r][2tx-pad+c], r, c = 0..3
  *     rows     t0 = d[0]-d[2]  t1 = d[1]+d[2]  t2 = d[2]-d[1]  t3 = d[1]-d[3]          (per column c)
  *     columns  v[xi][0] = t[xi][0]-t[xi][2]  v1 = t1+t2  v2 = t2-t1  v3 = t1-t3
  *     weights  h[xi][kx] over ky: h0 = g0, h1 = ((g0+g1)+g2)*0.5f, h2 = ((g0-g1)+g2)*0.5f, h3 = g2; then the same over kx
- *   m[xi][nu] = 0;  for chunk c0 / s / j / k:  m = fmaf(u[ci], v[ci], m),  ci = c0 + 8s + 4k + j
+ *   m[xi][nu] = 0;  for chunk c0 (16 cin) / j in 0..3 / g in 0..3:  m = fmaf(u[ci], v[ci], m),  ci = c0 + 4g + j
+ *             (v_mfma_f32_16x16x4_f32: MFMA j of a position consumes component j of the lanes' channel quads g = 0..3)
  *   y[i][j] = 0; for p = 4 xi + nu ascending: y[i][j] = fmaf(AT[i][xi]*AT[j][nu], m[xi][nu], y[i][j]), AT = [[1,1,1,0],[0,1,-1,-1]]
  *             (the kernel runs this chain on the matrix cores, v_mfma_f32_4x4x1: all 16 terms, zero coefficients included)
  *   out = max(fmaf(y, alpha, fmaf(bias, alpha, beta)), 0) */
-/* order 0: dcx_conv_wino2.h (v_mfma_f32_32x32x2: chunk / s / j / k, ci = c0 + 8s + 4k + j);
- * order 1: dcx_conv_wino2h.h (v_mfma_f32_16x16x4: chunk / j / g, ci = c0 + 4g + j) */
-static void conv_wino2_impl(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
-                            const float* alpha, const float* beta, int cout, int pad, float* y, int order) {
+void dcx_oracle_conv_wino2h_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
+                                  const float* alpha, const float* beta, int cout, int pad, float* y) {
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
     const int nty = (ho + 1) / 2, ntx = (wo + 1) / 2;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -138,9 +93,7 @@ static void conv_wino2_impl(const float* x, int n, int cin, int h, int w, const 
                     float m[4][4] = {{0.0f}};
                     for (int c0 = 0; c0 < cin; c0 += 16)
                         for (int step = 0; step < 16; ++step) {
-                                    /* order 0: step = 8s + 2j + k -> ci = c0 + 8s + 4k + j;  order 1: step = 4j + g -> ci = c0 + 4g + j */
-                                    const int ci = order == 0 ? c0 + 8 * (step >> 3) + 4 * (step & 1) + ((step >> 1) & 3)
-                                                              : c0 + 4 * (step & 3) + (step >> 2);
+                                    const int ci = c0 + 4 * (step & 3) + (step >> 2);      /* step = 4j + g */
                                     float d[4][4], t[4][4], v[4][4], hh[4][3], u[4][4];
                                     for (int r = 0; r < 4; ++r)
                                         for (int c = 0; c < 4; ++c) {
@@ -191,66 +144,13 @@ static void conv_wino2_impl(const float* x, int n, int cin, int h, int w, const 
                 }
 }
 
-void dcx_oracle_conv_wino2_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
-                                 const float* alpha, const float* beta, int cout, int pad, float* y) {
-    conv_wino2_impl(x, n, cin, h, w, wt, bias, alpha, beta, cout, pad, y, 0);
-}
-
-/* the same layer through dcx_conv_wino2h.h (half-size tiles, v_mfma_f32_16x16x4_f32): only the channel order inside a
- * 16-channel chunk differs */
-void dcx_oracle_conv_wino2h_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
-                                  const float* alpha, const float* beta, int cout, int pad, float* y) {
-    conv_wino2_impl(x, n, cin, h, w, wt, bias, alpha, beta, cout, pad, y, 1);
-}
-
-/* 3x3 (pad 1) + BN + ReLU over a nearest-x2 UP-SAMPLED input through the phase variant of the direct kernel
- * (deepcharuco_amd/csrc/dcx_conv_mfma.h, PH): x is the LOW-RESOLUTION input [n][cin][h][w], y is [n][cout][2h][2w].
- *   output (2Y+a, 2X+b): acc = 0; for chunk c0 / tap (dy, dx) in 2x2 (dy-major) / s / j / k:
- *       acc = fmaf(weff[a][b][dy][dx][ci], x[ci][Y - 1 + a + dy][X - 1 + b + dx] (0 outside), acc),  ci = c0 + 8s + 4k + j
- *   weff = the 3x3 weights summed over the kernel rows / columns that fall on the same low-resolution pixel: rows
- *   a = 0: dy 0 <- {0}, dy 1 <- {1, 2};  a = 1: dy 0 <- {0, 1}, dy 1 <- {2};  columns alike with b;  fp32, rows first, then
- *   columns, left to right (dcx_api.hip: pack_conv_ups2).
- *   y = max(fmaf(acc, alpha, fmaf(bias, alpha, beta)), 0) */
-void dcx_oracle_conv_ups2_exact(const float* x, int n, int cin, int h, int w, const float* wt, const float* bias,
-                                const float* alpha, const float* beta, int cout, float* y) {
-    static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};
-    const int ho = 2 * h, wo = 2 * w;
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int b = 0; b < n; ++b)
-        for (int co = 0; co < cout; ++co)
-            for (int oy = 0; oy < ho; ++oy)
-                for (int ox = 0; ox < wo; ++ox) {
-                    const int pa = oy & 1, pb = ox & 1, Y = oy >> 1, X = ox >> 1;
-                    float acc = 0.0f;
-                    for (int c0 = 0; c0 < cin; c0 += 16)
-                        for (int tap = 0; tap < 4; ++tap) {
-                            const int dy = tap >> 1, dx = tap & 1;
-                            const int iy = Y - 1 + pa + dy, ix = X - 1 + pb + dx;
-                            const int inb = iy >= 0 && iy < h && ix >= 0 && ix < w;
-                            for (int s = 0; s < 2; ++s)
-                                for (int j = 0; j < 4; ++j)
-                                    for (int k = 0; k < 2; ++k) {
-                                        const int ci = c0 + 8 * s + 4 * k + j;
-                                        const float* g = wt + ((size_t)co * cin + ci) * 9;
-                                        float r[3];
-                                        for (int kx = 0; kx < 3; ++kx) {
-                                            r[kx] = g[lo[pa][dy] * 3 + kx];
-                                            for (int ky = lo[pa][dy] + 1; ky <= hi[pa][dy]; ++ky) r[kx] = r[kx] + g[ky * 3 + kx];
-                                        }
-                                        float wv = r[lo[pb][dx]];
-                                        for (int kx = lo[pb][dx] + 1; kx <= hi[pb][dx]; ++kx) wv = wv + r[kx];
-                                        const float xv = inb ? x[(((size_t)b * cin + ci) * h + iy) * w + ix] : 0.0f;
-                                        acc = fmaf(wv, xv, acc);
-                                    }
-                        }
-                    y[(((size_t)b * cout + co) * ho + oy) * wo + ox] =
-                        fmaxf(fmaf(acc, alpha[co], fmaf(bias[co], alpha[co], beta[co])), 0.0f);
-                }
-}
-
-/* Phase variant as a 2-D Winograd F(2x2,2x2) per phase (deepcharuco_amd/csrc/dcx_conv_wino2p.h): 3x3 convolution (pad 1)
- * over a nearest-x2 up-sampled input, computed on the low-resolution tensor x [n][cin][h][w].
- *   Wp[a][b][dy][dx]: the 3x3 kernel's rows / columns pre-summed exactly as in dcx_oracle_conv_ups2_exact above;
+/* 3x3 convolution (pad 1) + BN + ReLU over a nearest-x2 UP-SAMPLED input as four phase convolutions, each a 2-D Winograd
+ * F(2x2,2x2) (deepcharuco_amd/csrc/dcx_conv_wino2p.h), computed on the low-resolution tensor x [n][cin][h][w]; y is
+ * [n][cout][2h][2w].  Up-sampling repeats every pixel 2x2, so the 3x3 window of output (2Y+a, 2X+b) sees a 2x2 block of
+ * distinct low-resolution pixels and each phase (a, b) is a 2x2-tap convolution with weights
+ *   Wp[a][b][dy][dx] = the 3x3 kernel summed over the rows / columns that fall on the same low-resolution pixel: rows
+ *   a = 0: dy 0 <- {ky 0}, dy 1 <- {ky 1, 2};  a = 1: dy 0 <- {ky 0, 1}, dy 1 <- {ky 2};  columns alike with b;  fp32, rows
+ *   first, then columns, left to right (dcx_api.hip: pack_conv_ups2);
  *   Wc[dy] = (Wp[dy][0], Wp[dy][0] + Wp[dy][1], Wp[dy][1]);  U[.][nu] = (Wc[0][nu], Wc[0][nu] + Wc[1][nu], Wc[1][nu]);
  *   per phase (a, b) and 2x2 tile of low-resolution positions (y0, x0), y0, x0 even:
  *     d[r][s] = x[y0 - (1-a) + r][x0 - (1-b) + s] (0 outside);  t[0] = d[0] - d[1], t[1] = d[1], t[2] = d[2] - d[1] (per column s);

@@ -1,0 +1,149 @@
+"""Worker of tests/test_gpu_sharded.py::test_world8_*: one rank of an EIGHT-rank run of the product path (real HIP kernels).
+
+BASELINE configs[3] (bs=1024 320x240 over 8 GPUs) and configs[4] (bs=256 1280x960, 16 corners per frame, over 8 GPUs) at
+their true world size, as far as one GPU allows: eight gloo ranks time-slice the one visible GPU (RCCL needs one GPU per
+rank; with >= 8 GPUs visible pass backend "nccl").  Modes:
+
+  cfg4   every rank runs `infer_batches_sharded` on 1,024 frames of 320x240 (128 per rank = the per-GPU load of
+         configs[3]), two batches in flight, then on a ragged 1,021-frame batch (128 x5 + 127 x3);
+  cfg5   32 frames of 1280x960 with exactly 16 corners each, kmax = 16 (4 per rank: configs[4] reduced 8x in batch only).
+
+Rank 0 compares frames of EVERY rank's shard (first, last and two inner frames; for the ragged batch the frames on both
+sides of every shard boundary) with the oracle and writes the verdict.  Frame i of a batch depends only on (kind, seed + i),
+so every rank renders just its own shard and rank 0 re-renders what it checks."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from deepcharuco_amd import weights as W  # noqa: E402
+from deepcharuco_amd import workload as WL  # noqa: E402
+from deepcharuco_amd.models.net import dcModel, lModel  # noqa: E402
+from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet  # noqa: E402
+from deepcharuco_amd.sharding import infer_batches_sharded, shard_range  # noqa: E402
+
+SEED = 42000
+
+
+def same(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def local_batch(kind, seed, n, h, w, rank, world):
+    """(n,h,w) array whose rows [lo,hi) of THIS rank's shard are rendered; the rest stays blank (never read by this rank)."""
+    lo, hi = shard_range(n, rank, world)
+    out = np.zeros((n, h, w), np.uint8)
+    if hi > lo:
+        out[lo:hi] = W.synthetic_frames(kind, seed + lo, hi - lo, h, w)
+    return out
+
+
+def main():
+    mode, backend, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % ndev if backend == "gloo" else local)
+    torch.cuda.set_device(dev)
+    torch.set_num_threads(4 if rank else 16)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    sd_rn = W.synthetic_state_dict("refinenet", 1235)
+    verdict = dict(mode=mode, backend=backend, world=world, devices=ndev)
+    if mode == "cfg4":
+        n, h, w, kmax = 128 * world, 240, 320, 64
+        calib = torch.from_numpy(W.synthetic_frames("board", SEED, 32, h, w)).to(dev)      # same frames on every rank
+        sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), calib, dev)
+        dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+        full = local_batch("board", SEED, n, h, w, rank, world)
+        # two full batches in flight (the second = frames of seed + 5000), then the ragged one as its own call
+        full2 = local_batch("board", SEED + 5000, n, h, w, rank, world)
+        res_a, res_b = list(infer_batches_sharded([full, full2], 16, dc, rn, kmax=kmax))
+        n_rag = n - 3                                                    # 1,021 at world 8: 128 x5 + 127 x3
+        rag = local_batch("board", SEED + 9000, n_rag, h, w, rank, world)
+        (res_r,) = list(infer_batches_sharded([rag], 16, dc, rn, kmax=kmax))
+        if rank == 0:
+            from oracle import deepcharuco_oracle as O
+            t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+            ora = lambda seed, i: O.infer_image(None, 16, t_dc, t_rn, gray=W.synthetic_frames("board", seed + i, 1, h, w)[0])
+            checked = corners = bad = 0
+            per_rank = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                idx = sorted({lo, hi - 1, lo + (hi - lo) // 3, lo + 2 * (hi - lo) // 3})
+                nbad = 0
+                for i in idx:
+                    for res, seed in ((res_a, SEED), (res_b, SEED + 5000)):
+                        e = ora(seed, i)
+                        nbad += not same(res[i], e)
+                        corners += 0 if e.ndim == 1 else e.shape[0]
+                        checked += 1
+                lo, hi = shard_range(n_rag, r, world)
+                for i in sorted({lo, hi - 1}):
+                    e = ora(SEED + 9000, i)
+                    nbad += not same(res_r[i], e)
+                    corners += 0 if e.ndim == 1 else e.shape[0]
+                    checked += 1
+                per_rank.append(int(nbad))
+                bad += nbad
+            counts = [0 if a.ndim == 1 else a.shape[0] for a in res_a]
+            verdict.update(frames=n, frames_ragged=n_rag, split=[shard_range(n, r, world) for r in range(world)],
+                           split_ragged=[shard_range(n_rag, r, world) for r in range(world)],
+                           results_returned=[len(res_a), len(res_b), len(res_r)], frames_checked=checked, corners_checked=corners,
+                           mismatched=int(bad), mismatched_per_rank=per_rank,
+                           mean_corners_per_frame=float(np.mean(counts)), max_corners=int(max(counts)))
+    elif mode == "cfg5":
+        per, h, w, kmax = 4, 960, 1280, 16
+        n = per * world
+        calib = torch.from_numpy(W.synthetic_frames("board4", SEED, 8, h, w)).to(dev)
+        sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), calib, dev)
+        dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+        pick = lambda r: WL.select_fixed_k_frames("board4", SEED + 100000 * (r + 1), per, h, w, 16, dc, dev, chunk=8)[0]
+        mine = pick(rank)
+        batch = np.zeros((n, h, w), np.uint8)
+        batch[rank * per:(rank + 1) * per] = mine
+        batch2 = np.zeros((n, h, w), np.uint8)                         # second batch in flight: the shard's frames rotated by one
+        batch2[rank * per:(rank + 1) * per] = np.roll(mine, 1, axis=0)
+        res_a, res_b = list(infer_batches_sharded([batch, batch2], 16, dc, rn, kmax=kmax))
+        if rank == 0:
+            from oracle import deepcharuco_oracle as O
+            t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+            checked = corners = bad = 0
+            per_rank, ks = [], []
+            for r in range(world):
+                fr = pick(r)                                           # same kernels, same weights -> same selection as rank r made
+                nbad = 0
+                for j in (0, per - 1):
+                    e = O.infer_image(None, 16, t_dc, t_rn, gray=fr[j])
+                    nbad += not same(res_a[r * per + j], e)
+                    ks.append(0 if e.ndim == 1 else e.shape[0])
+                    checked += 1
+                nbad += int(not same(res_b[r * per + 1], res_a[r * per + 0])) + int(not same(res_b[r * per + 0], res_a[r * per + per - 1]))
+                corners += sum(ks[-2:])
+                per_rank.append(int(nbad))
+                bad += nbad
+            verdict.update(frames=n, height=h, width=w, kmax=kmax, frames_checked=checked, corners_checked=corners,
+                           corners_per_frame_seen=sorted(set(ks)), mismatched=int(bad), mismatched_per_rank=per_rank,
+                           all_frames_have_16=bool(all(a.ndim == 2 and a.shape[0] == 16 for a in res_a)))
+    else:
+        raise SystemExit(f"unknown mode {mode}")
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(verdict, f)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        sys.exit(0 if verdict.get("mismatched", 1) == 0 else 4)
+
+
+if __name__ == "__main__":
+    main()

@@ -115,8 +115,7 @@ def _conv_layer(x_nchw, w, b, bn, pad, ups, pool, ks=3):
 
 def _family(kernel_name):
     """Which exact-order restatement (oracle/conv_exact.c) a kernel instantiation follows."""
-    return (5 if "wino2p" in kernel_name else 3 if ",PH>>" in kernel_name else 4 if "wino2h" in kernel_name
-            else 2 if "wino2" in kernel_name else 1 if "wino" in kernel_name else 0)
+    return "w2p" if "wino2p" in kernel_name else "w2h" if "wino2h" in kernel_name else "direct"
 
 
 def _conv_ref(x, w, b, bn, pad, ups, pool):
@@ -146,7 +145,9 @@ CONV_CASES = [
     ("A_10x20_valid", 3, 64, 64, 22, 22, 0, 0, 0, 3, True),
     ("B_6x18_valid", 3, 64, 128, 20, 20, 0, 0, 0, 3, True),
     ("B_8x16_valid_pool", 3, 128, 128, 18, 18, 0, 0, 1, 3, True),
-    ("C_8x8", 5, 128, 128, 8, 8, 1, 0, 0, 3, True),
+    ("C_8x8", 5, 128, 128, 8, 8, 1, 0, 0, 3, True),               # odd image count: the grouped (two 8x8 maps) tiles' last item is half empty
+    ("C_8x8_64to128_even", 6, 64, 128, 8, 8, 1, 0, 0, 3, True),
+    ("G_6x6_map_in_grouped_tile", 3, 64, 64, 6, 6, 1, 0, 0, 3, True),
     ("B_8x16_ups", 3, 128, 128, 8, 8, 1, 1, 0, 3, True),
     ("A_8x32_ups_128to64", 2, 128, 64, 16, 16, 1, 1, 0, 3, True),
     ("P_ups_32x32_64to64", 3, 64, 64, 32, 32, 1, 1, 0, 3, True),
@@ -197,7 +198,7 @@ def test_conv_layer_bit_exact_vs_c_restatement(dev, case):
     ho, wo = (h << ups) + 2 * pad - (ks - 1), (w << ups) + 2 * pad - (ks - 1)
     picked = _lib.lib().dcx_conv_pick_name_ups(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1, int(ups)).decode()
     ref = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
-                     pad=pad, ups=bool(ups), pool=bool(pool), wino=_family(picked))   # each kernel family has its own order
+                     pad=pad, ups=bool(ups), pool=bool(pool), family=_family(picked))   # each kernel family has its own order
     nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     _report(f"conv_layer_bitexact/{name}", dict(kernel=picked[picked.find("dcx_conv_") + 9:], mismatching_elements=nbad,
                                                 max_abs=float(np.abs(got - ref).max())))
@@ -205,10 +206,11 @@ def test_conv_layer_bit_exact_vs_c_restatement(dev, case):
 
 
 def test_every_conv_instantiation_bit_exact(dev, monkeypatch):
-    """The cost model picks the small S tile for test-sized layers, so the parametrised tests above do not reach the
-    big-tile instantiations.  DCX_FORCE_CFG walks EVERY instantiation of the table over every shape variant it can
-    run (padding / valid / up-sampled / pooled / partial tiles) and compares bit for bit with the restatement of
-    that kernel's summation order (direct or 1-D Winograd)."""
+    """The parametrised tests above only reach the instantiations the family rule + cost model pick for test-sized layers.
+    DCX_FORCE_CFG walks EVERY instantiation of the table (all tiles of the three families, the grouped-map variants) over
+    every shape variant it can run (padding / valid / up-sampled / pooled / partial tiles / odd image counts) and compares
+    bit for bit with the restatement of that FAMILY's summation order: all tiles of a family must produce the same bits --
+    that is what makes the default path batch-invariant."""
     from oracle.conv_exact import conv_exact
     from deepcharuco_amd import _lib
     L = _lib.lib()
@@ -218,7 +220,7 @@ def test_every_conv_instantiation_bit_exact(dev, monkeypatch):
         if nm == "?":
             break
         names.append(nm)
-    assert len(names) >= 20
+    assert len(names) >= 20 and sum("wino2h" in n_ for n_ in names) >= 5
     ran = {}
     for case in CONV_CASES:
         name, n, cin, cout, h, w, pad, ups, pool, ks, has_bn = case
@@ -239,12 +241,12 @@ def test_every_conv_instantiation_bit_exact(dev, monkeypatch):
             if L.dcx_conv_pick_name_ups(n, cin, ho, wo, cout, ks, int(pool), 0 if has_bn else 1, int(ups)).decode() != cfg:
                 continue      # this instantiation cannot run this layer (kernel size / pooling / cout tile / up-sampling)
             got = _conv_layer(x.to(dev), wt, b, bn, pad, ups, pool, ks).cpu().numpy()
-            wino = _family(cfg)
-            if wino not in refs:
-                refs[wino] = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
-                                        pad=pad, ups=bool(ups), pool=bool(pool), wino=wino)
-            nbad = int((got.view(np.uint32) != refs[wino].view(np.uint32)).sum())
-            assert nbad == 0, f"{cfg} on {name}: {nbad} of {got.size} elements differ (max abs {np.abs(got - refs[wino]).max()})"
+            fam = _family(cfg)
+            if fam not in refs:
+                refs[fam] = conv_exact(x.numpy(), wt.numpy(), b.numpy(), None if bn is None else [t.numpy() for t in bn],
+                                       pad=pad, ups=bool(ups), pool=bool(pool), family=fam)
+            nbad = int((got.view(np.uint32) != refs[fam].view(np.uint32)).sum())
+            assert nbad == 0, f"{cfg} on {name}: {nbad} of {got.size} elements differ (max abs {np.abs(got - refs[fam]).max()})"
             ran[cfg] = ran.get(cfg, 0) + 1
     monkeypatch.delenv("DCX_FORCE_CFG")
     _report("conv_instantiations_bitexact", ran)
@@ -627,7 +629,7 @@ def test_two_streams_share_one_model_pair(dev):
 
 
 def test_hazard_soak_repeated_runs_are_bit_identical(dev):
-    """The MFMA kernels pad their own hazards around inline asm (dcx_conv_wino2.h): 60 repeated bs=32 runs plus three
+    """The MFMA kernels pad their own hazards around inline asm (dcx_conv_wino2h.h): 60 repeated bs=32 runs plus three
     other batch sizes must reproduce one SHA-256 per batch size (packed corner lists of every frame), and the heat-map
     / logits entry points must be bit-stable over 20 runs."""
     import hashlib
@@ -714,15 +716,106 @@ def test_hipgraph_replay_equals_eager_launches(dev, golden_tiny):
         gp.run(imgs[2][None])
 
 
-def test_deterministic_mode_is_batch_invariant(dev):
-    """by default the kernel family depends on the launch size, so a frame's logits may differ in the last bits
-    between B=1 and B=32.  set_deterministic(True) pins the direct kernels: logits bit-identical alone / inside a batch."""
+def test_graph_cache_threads_modes_and_lifetime(dev, golden_tiny):
+    """(1) concurrent infer_image callers on one model pair get their own GraphedPipeline (no shared staging
+    buffers) and each returns ITS image's corners; (2) a mode switch (set_deterministic) drops the graphs captured under the
+    previous mode; (3) graphs are bypassed while timing is on; (4) the cache lives on the detector and dies with it."""
+    import gc
+    import threading
+    import weakref
+    import deepcharuco_amd.inference as I
+    from deepcharuco_amd import _lib, graph as G
+    dc, rn = _models(golden_tiny, dev)
+    t_dc, t_rn = O.to_torch_state_dict(golden_tiny.sd_dc), O.to_torch_state_dict(golden_tiny.sd_rn)
+    imgs = [np.repeat(W.synthetic_frames("noise", 50 + i, 1, 64, 96)[0][..., None], 3, axis=2) for i in range(4)]
+    exp = [O.infer_image(im, 16, t_dc, t_rn) for im in imgs]
+    assert len({e.tobytes() for e in exp}) == 4
+    out, errs = {}, []
+
+    def worker(i):
+        try:
+            for _ in range(25):
+                kp, _ = I.infer_image(imgs[i], 16, dc, rn, device="cuda")
+                if not (kp.shape == exp[i].shape and np.array_equal(kp, exp[i])):
+                    errs.append(i)
+            out[i] = threading.get_ident()
+        except Exception as e:      # noqa
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and len(out) == 4
+    cache = dc.model._graph_cache
+    assert len({k[-1] for k in cache}) == 4                                  # one pipeline per calling thread
+    # (2) mode switch clears, and the next call captures under the new mode
+    I.set_deterministic(True)
+    try:
+        assert len(cache) == 0
+        kp, _ = I.infer_image(imgs[0], 16, dc, rn, device="cuda")
+        assert np.array_equal(kp, exp[0]) and [k[-2] for k in cache] == [1]
+    finally:
+        I.set_deterministic(False)
+    assert len(cache) == 0
+    # (3) timing on -> eager launches, cache untouched
+    L = _lib.lib()
+    L.dcx_set_timing(1)
+    try:
+        assert not G.graphs_usable()
+        kp, _ = I.infer_image(imgs[1], 16, dc, rn, device="cuda")
+        assert np.array_equal(kp, exp[1]) and len(cache) == 0
+    finally:
+        L.dcx_set_timing(0)
+    # (4) lifetime: a model that ran graphed calls is freed when the caller drops it
+    dc2, rn2 = _models(golden_tiny, dev)
+    I.infer_image(imgs[2], 16, dc2, rn2, device="cuda")
+    ref = weakref.ref(dc2.model)
+    del dc2, rn2
+    gc.collect()
+    assert ref() is None
+
+
+def test_default_mode_is_batch_invariant(dev):
+    """the kernel family of a layer depends on the layer only, and all tiles of a family give
+    the same bits, so in DEFAULT mode a frame's logits and corners are bit-identical alone and inside any batch:
+    infer_batch(frames)[b] == infer_image(frames[b]) structurally (reference semantics: inference.py:32-70 is per frame)."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 4321, 128, 240, 320)
+    sd = _calibrated(1234, frames[:16], target_per_frame=16)
+    det = dcModel(16, sd, dev)
+    d = torch.from_numpy(frames).to(dev)
+    full = det.forward_u8(d)                                    # B = 128
+    for B in (1, 7, 32):
+        part = det.forward_u8(d[:B])
+        assert torch.equal(part["loc"], full["loc"][:B]) and torch.equal(part["ids"], full["ids"][:B]), B
+    for b in (5, 77, 127):                                      # a frame alone, wherever it sat in the batch
+        one = det.forward_u8(d[b:b + 1])
+        assert torch.equal(one["loc"][0], full["loc"][b]) and torch.equal(one["ids"][0], full["ids"][b]), b
+    # the whole path (detector, decode, gather, RefineNet with 16 / 112 / 512 / 2,048 live patches, sub-pixel arg-max)
+    dc, rn = lModel(det), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
+    all128 = infer_batch(frames, 16, dc, rn)
+    assert sum(r.shape[0] for r in all128 if r.ndim == 2) > 1500
+    for B in (1, 7, 32):
+        part = infer_batch(frames[:B], 16, dc, rn)
+        assert all(a.shape == b_.shape and np.array_equal(a, b_) for a, b_ in zip(part, all128[:B])), B
+    # RefineNet heat-maps of the same patches in launches of different size
+    patches = torch.randn(300, 24, 24, generator=torch.Generator().manual_seed(3)).to(dev)
+    heat = rn.model.forward(patches[:, None])
+    for K in (1, 16, 113):
+        assert torch.equal(rn.model.forward(patches[:K, None]), heat[:K]), K
+
+
+def test_deterministic_mode_runs_the_direct_family(dev):
+    """set_deterministic(True) pins the direct kernels (every multiply-add of the layers as written): still batch-invariant,
+    logits within fp32 re-ordering noise of the default families', identical decisions."""
     from deepcharuco_amd import _lib
     from deepcharuco_amd.inference import set_deterministic
     from deepcharuco_amd.models.net import dcModel
     frames = W.synthetic_frames("board", 4321, 32, 240, 320)
     det = dcModel(16, W.synthetic_state_dict("detector", 1234), dev)
     d = torch.from_numpy(frames).to(dev)
+    dflt = det.forward_u8(d)
     try:
         set_deterministic(True)
         assert _lib.lib().dcx_get_deterministic() == 1
@@ -733,11 +826,9 @@ def test_deterministic_mode_is_batch_invariant(dev):
             assert torch.equal(one["loc"][0], full["loc"][b]) and torch.equal(one["ids"][0], full["ids"][b])
     finally:
         set_deterministic(False)
-    assert b"wino2" in _lib.lib().dcx_conv_pick_name(32, 64, 240, 320, 64, 3, 1, 0)
-    dflt = det.forward_u8(d)
-    one = det.forward_u8(d[:1])
-    _report("default_mode_b1_vs_b32_logit_diff", float((one["loc"][0] - dflt["loc"][0]).abs().max()))
-    assert (one["loc"][0] - dflt["loc"][0]).abs().max() <= LOGIT_ATOL
+    assert b"wino2h" in _lib.lib().dcx_conv_pick_name(32, 64, 240, 320, 64, 3, 1, 0)
+    _report("default_vs_direct_family_logit_diff", float((full["loc"] - dflt["loc"]).abs().max()))
+    assert (full["loc"] - dflt["loc"]).abs().max() <= LOGIT_ATOL and (full["ids"] - dflt["ids"]).abs().max() <= LOGIT_ATOL
 
 
 def test_colour_bgr_input_through_the_gpu_path(dev, golden_tiny):
@@ -923,11 +1014,11 @@ print("RESULT", n, h.hexdigest())
 
 
 def test_kernel_families_give_identical_corners(dev):
-    """The same 32 frames through the convolution kernel families -- direct only, 1-D Winograd, 2-D Winograd + phase
-    kernels (the default), the default without the phase kernels and with the flat item walk, deterministic mode -- must
-    give identical corner lists (ids, integer cells, sub-pixel xy): the families differ in fp32 rounding
-    (each is bit-exact against ITS restatement), and the arg-max outputs must not notice.  Each family runs in its own
-    process because the switches are read once per process."""
+    """The same 32 frames through the default path (2-D Winograd + phase x Winograd families), the default with the flat item
+    walk / one workgroup per CU, and deterministic mode (direct family: every multiply-add of the layers as written) must
+    give identical corner lists (ids, integer cells, sub-pixel xy): the families differ in fp32 rounding (each is bit-exact
+    against ITS restatement), and the arg-max outputs must not notice.  Each variant runs in its own process because the
+    switches are read once per process."""
     import subprocess
     import sys
     frames = np.concatenate([W.synthetic_frames("noise", 4100, 16, 240, 320), W.synthetic_frames("board", 5100, 16, 240, 320)])
@@ -935,9 +1026,7 @@ def test_kernel_families_give_identical_corners(dev):
     delta = float(sd["convDb.bias"][16] - W.synthetic_state_dict("detector", 2024)["convDb.bias"][16])
     script = _FAMILY_SCRIPT.format(repo=REPO, delta=delta)
     results = {}
-    for name, env in (("direct", {"DCX_WINO": "0", "DCX_WINO2": "0", "DCX_UPS2": "0"}), ("wino1d", {"DCX_WINO2": "0"}),
-                      ("wino2d", {}), ("no_phase_flat_walk", {"DCX_UPS2": "0", "DCX_XCD_WALK": "0"}),
-                      ("plain_phase_no_half_tiles", {"DCX_UPS2W": "0", "DCX_WINO2H": "0"}),
+    for name, env in (("default", {}), ("flat_walk", {"DCX_XCD_WALK": "0"}), ("one_workgroup_per_cu", {"DCX_OCC": "1"}),
                       ("deterministic", {"DCX_DETERMINISTIC": "1"})):
         e = dict(os.environ)
         e.pop("DCX_FORCE_CFG", None)
@@ -947,7 +1036,7 @@ def test_kernel_families_give_identical_corners(dev):
         assert line, f"{name}: {out.stderr[-2000:]}"
         results[name] = line[0].split()[1:]
     _report("kernel_families", {k: dict(corners=int(v[0]), sha256=v[1][:16]) for k, v in results.items()})
-    assert int(results["wino2d"][0]) > 200
+    assert int(results["default"][0]) > 200
     assert len({tuple(v) for v in results.values()}) == 1, results
 
 

@@ -38,6 +38,43 @@ def _launch(backend, world, tmp_path):
     return v
 
 
+def _launch8(mode, tmp_path, timeout=1500):
+    """Eight ranks; gloo on a 1-GPU box (the ranks time-slice the GPU), RCCL when eight GPUs are visible."""
+    backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
+    out = str(tmp_path / f"world8_{mode}.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    env.pop("DCX_FORCE_CFG", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "tests", "sharded_world8_worker.py"), mode, backend, out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    v = json.load(open(out))
+    rep = os.path.join(REPO, "gpurun_out")
+    os.makedirs(rep, exist_ok=True)
+    with open(os.path.join(rep, f"sharded_world8_{mode}_{backend}_report.json"), "w") as f:
+        json.dump(v, f, indent=1)
+    return v
+
+
+def test_world8_cfg4_full_size_every_rank_checked(tmp_path):
+    """BASELINE configs[3] at its true world size: 1,024 frames of 320x240 over EIGHT ranks (128 each) through
+    infer_batches_sharded, two batches in flight, plus the ragged 1,021-frame split; frames of every rank's shard vs the oracle."""
+    v = _launch8("cfg4", tmp_path)
+    assert v["world"] == 8 and v["frames"] == 1024 and v["results_returned"] == [1024, 1024, 1021]
+    assert [b - a for a, b in v["split"]] == [128] * 8
+    assert [b - a for a, b in v["split_ragged"]] == [128] * 5 + [127] * 3
+    assert v["mismatched"] == 0 and v["mismatched_per_rank"] == [0] * 8 and v["frames_checked"] >= 8 * 10
+    assert v["corners_checked"] > 500
+
+
+def test_world8_cfg5_reduced_every_rank_checked(tmp_path):
+    """BASELINE configs[4] reduced in batch only: 8 ranks x 4 frames of 1280x960, exactly 16 corners per frame, kmax = 16."""
+    v = _launch8("cfg5", tmp_path)
+    assert v["world"] == 8 and v["frames"] == 32 and v["all_frames_have_16"] and v["corners_per_frame_seen"] == [16]
+    assert v["mismatched"] == 0 and v["mismatched_per_rank"] == [0] * 8 and v["frames_checked"] >= 16
+
+
 def test_two_ranks_on_one_gpu_gloo_real_kernels(tmp_path):
     v = _launch("gloo", 2, tmp_path)
     assert v["world"] == 2 and v["split"] == [[0, 6], [6, 11]]

@@ -1,10 +1,10 @@
 """Kernel bring-up aid: run ONE conv instantiation (DCX_FORCE_CFG) on a few shapes and locate elements that differ from its
-exact-order C restatement.  usage (MI355X): python tools/conv_debug.py "dcx_conv_wino2_kernel<DcxWino2Cfg<16,16,0>>" """
+exact-order C restatement.  usage (MI355X): python tools/conv_debug.py "dcx_conv_wino2h_kernel<DcxWino2hCfg<8,16,0,1>>" """
 import os, sys, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-os.environ["DCX_FORCE_CFG"] = sys.argv[1] if len(sys.argv) > 1 else "dcx_conv_wino2_kernel<DcxWino2Cfg<16,16,0>>"
+os.environ["DCX_FORCE_CFG"] = sys.argv[1] if len(sys.argv) > 1 else "dcx_conv_wino2h_kernel<DcxWino2hCfg<8,16,0,1>>"
 import test_gpu_parity as T
 from oracle.conv_exact import conv_exact
 dev = torch.device("cuda", 0)
@@ -17,7 +17,7 @@ for (n, cin, cout, h, w) in [(1, 32, 64, 16, 16), (1, 64, 64, 16, 16), (1, 64, 6
     got = T._conv_layer(x.to(dev), wt, b, bn, 1, 0, False, 3).cpu().numpy()
     cfg = os.environ["DCX_FORCE_CFG"]
     ref = conv_exact(x.numpy(), wt.numpy(), b.numpy(), [t.numpy() for t in bn], pad=1,
-                     wino=2 if "wino2" in cfg else 1 if "wino" in cfg else 0)
+                     family=T._family(cfg))
     bad = got.view(np.uint32) != ref.view(np.uint32)
     print((n, cin, cout, h, w), "bad", int(bad.sum()), "of", bad.size, "maxabs", float(np.abs(got - ref).max()))
     if bad.any():

@@ -30,33 +30,18 @@ def lib_name(rocprof_name):
     if m:   # <TH, TW, EPI, G>
         f = [x.strip() for x in m.group(1).split(",")]
         epi = {"0": "DCX_EPI_BNRELU", "2": "DCX_EPI_HEAT"}[f[2] if len(f) > 2 else "0"]
-        grp = ("," + f[3]) if len(f) > 3 and f[3] != "1" else ""
-        return "dcx_conv_wino2p_kernel<DcxWino2pCfg<" + f[0] + "," + f[1] + "," + epi + grp + ">>"
+        return "dcx_conv_wino2p_kernel<DcxWino2pCfg<" + f[0] + "," + f[1] + "," + epi + "," + (f[3] if len(f) > 3 else "1") + ">>"
     m = re.search(r"DcxWino2hCfg<([^>]*)>", rocprof_name)
-    if m:   # <TH, TW, POOL, EPI>
+    if m:   # <TH, TW, POOL, G>
         f = [x.strip() for x in m.group(1).split(",")]
         f[2] = "1" if f[2] == "true" else "0"
-        return "dcx_conv_wino2h_kernel<DcxWino2hCfg<" + ",".join(f[:3]) + ">>"
-    m = re.search(r"DcxWino2Cfg<([^>]*)>", rocprof_name)
-    if m:   # <TH, TW, POOL, EPI>
-        f = [x.strip() for x in m.group(1).split(",")]
-        f[2] = "1" if f[2] == "true" else "0"
-        epi = f[3] if len(f) > 3 else "0"
-        return "dcx_conv_wino2_kernel<DcxWino2Cfg<" + ",".join(f[:3]) + (",DCX_EPI_HEAT" if epi == "2" else "") + ">>"
-    m = re.search(r"DcxWinoCfg<([^>]*)>", rocprof_name)
-    if m:   # <WM, WN, TH, TW, POOL, EPI> -> the name dcx_profile_kernel_name() reports
-        f = [x.strip() for x in m.group(1).split(",")]
-        f[4] = "1" if f[4] == "true" else "0"
-        epi = f[5] if len(f) > 5 else "0"
-        return "dcx_conv_wino_kernel<DcxWinoCfg<" + ",".join(f[:5]) + (",DCX_EPI_HEAT" if epi == "2" else "") + ">>"
+        return "dcx_conv_wino2h_kernel<DcxWino2hCfg<" + ",".join(f[:3]) + "," + (f[3] if len(f) > 3 else "1") + ">>"
     m = re.search(r"DcxConvCfg<([^>]*)>", rocprof_name)
     if not m:
         return None
     f = [x.strip() for x in m.group(1).split(",")]
     f[7] = "1" if f[7] == "true" else "0"
     f[8] = {"0": "DCX_EPI_BNRELU", "1": "DCX_EPI_RAW", "2": "DCX_EPI_HEAT"}[f[8]]
-    if len(f) > 9:      # phase variant: <..., EPI, true> -> the library's "...,EPI,PH"
-        f = f[:9] + (["PH"] if f[9] == "true" else [])
     return "dcx_conv_mfma_kernel<DcxConvCfg<" + ",".join(f) + ">>"
 
 
