@@ -11,8 +11,8 @@ The reference derives both metric classes from ``torchmetrics.Metric`` (training
 DDP reduction); here they are plain accumulators with the same ``update`` / ``compute`` contract.  What feeds them is
 this repo's hot path: ``update`` decodes GPU logits with the HIP decode kernel (``models.model_utils.pred_to_keypoints``)
 and takes heat-map arg-maxes with ``speedy_bargmax2d``; ``update_keypoints`` takes ``infer_batch`` results directly.
-The per-id matching arithmetic is host-side torch, statement for statement the reference's (including its assumption
-that an id occurs once per target frame -- a duplicated target id fails exactly as it does there).
+The per-id matching arithmetic is host-side torch / numpy with the reference's semantics (including its assumption that an id
+occurs once per target frame -- a duplicated target id behaves exactly as it does there).
 """
 from __future__ import annotations
 
@@ -26,16 +26,14 @@ __all__ = ["DC_Metrics", "Refinenet_Metrics", "label_to_keypoints", "compute_l2_
 
 
 def label_to_keypoints(loc: torch.Tensor, ids: torch.Tensor, dust_bin_ids: int):
-    """metrics.py:25-35: label maps (N,Hc,Wc) -> (kpts (K,2) float32 (x,y), ids (K,)), raster order."""
-    assert loc.ndim == 3 and ids.ndim == 3
+    """metrics.py:25-35: label maps (N,Hc,Wc) -> (kpts (K,2) float32 (x,y), ids (K,)), raster order (frame, row, column)."""
+    if loc.ndim != 3 or ids.ndim != 3:
+        raise AssertionError("label maps must be (N, Hc, Wc)")
     loc, ids = loc.cpu(), ids.cpu()
-    mask = ids != dust_bin_ids
-    roi = torch.argwhere(mask)
-    ids_found = ids[mask]
-    region_pixel = loc[mask]
-    xs = 8 * roi[:, -1] + (region_pixel % 8)
-    ys = 8 * roi[:, -2] + torch.div(region_pixel, 8, rounding_mode="floor")
-    return torch.cat((xs.unsqueeze(1), ys.unsqueeze(1)), dim=1).float(), ids_found
+    n, cy, cx = torch.nonzero(ids != dust_bin_ids, as_tuple=True)       # row-major: the order the reference's masks produce
+    cell = loc[n, cy, cx]                                               # 0..63 inside the 8x8 cell: x + 8 y
+    kpts = torch.stack((8 * cx + cell % 8, 8 * cy + cell // 8), dim=1).to(torch.float32)
+    return kpts, ids[n, cy, cx]
 
 
 def _pred_to_keypoints(loc_hat: torch.Tensor, ids_hat: torch.Tensor, dust_bin_ids: int):
@@ -201,32 +199,44 @@ def keypoints_from_results(res: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]
 # /root/reference/src/utils.py
 
 def compute_l2_distance(keypoints, ids, target_keypoints, target_ids):
-    """utils.py:6-30 (numpy): per target slot, the worst distance between the key-points and the target of that id."""
-    distances = np.zeros((len(target_ids),))
-    if distances.size == 0:
+    """utils.py:6-30.  One slot per target key-point; slot r (r = rank of an id among the sorted distinct target ids) holds
+    the WORST L2 distance between the key-points carrying that id and its target; slots of ids nobody predicted stay 0, as do
+    the trailing slots when ids repeat among the targets.  ``None`` without targets.  Vectorised: one scatter-max over the
+    predictions instead of a Python loop over ids (an id that occurs several times among the targets is paired element by
+    element like the reference's broadcast, and fails the same way when the counts disagree)."""
+    keypoints, target_keypoints = np.asarray(keypoints), np.asarray(target_keypoints)
+    ids, target_ids = np.asarray(ids), np.asarray(target_ids)
+    out = np.zeros((len(target_ids),))
+    if out.size == 0:
         return None
-    for i, id_ in enumerate(np.unique(target_ids)):
-        mask = np.nonzero(ids == id_)[0]
-        target_mask = np.nonzero(target_ids == id_)[0]
-        if mask.size == 0 or target_mask.size == 0:
-            continue
-        dist = np.linalg.norm(keypoints[mask] - target_keypoints[target_mask], ord=2, axis=1)
-        distances[i] = np.max(dist)
-    return distances
+    uniq, first, count = np.unique(target_ids, return_index=True, return_counts=True)
+    rank = np.minimum(np.searchsorted(uniq, ids), len(uniq) - 1)
+    known = uniq[rank] == ids                                     # predictions whose id exists among the targets
+    easy = known & (count[rank] == 1)
+    if easy.any():
+        worst = np.linalg.norm(keypoints[easy] - target_keypoints[first[rank[easy]]], ord=2, axis=1)
+        np.maximum.at(out, rank[easy], worst)
+    for r in np.nonzero(count > 1)[0]:                            # repeated target id: numpy pairs rows one to one
+        mine = np.nonzero(ids == uniq[r])[0]
+        if mine.size:
+            out[r] = np.linalg.norm(keypoints[mine] - target_keypoints[target_ids == uniq[r]], ord=2, axis=1).max()
+    return out
 
 
 def pixel_error(kpts_raw, kpts_ref, kpts_target, verbose: bool = True):
     """utils.py:33-52: mean pixel error of the detector's raw key-points and of the RefineNet-refined ones against the
-    targets ((K,3) [x,y,id] arrays); ``(None, None)`` when a raw id is not among the target ids."""
-    if not set(kpts_raw[:, 2]).issubset(set(kpts_target[:, 2])):
+    targets ((K,3) [x,y,id] arrays); ``(None, None)`` when a raw id is not among the target ids.  Returns
+    ``(mean raw error, mean refined error)``; ``verbose`` prints a three-line summary."""
+    raw_xy, raw_id = kpts_raw[:, :2], kpts_raw[:, 2]
+    ref_xy, ref_id = kpts_ref[:, :2], kpts_ref[:, 2]
+    tgt_xy, tgt_id = kpts_target[:, :2], kpts_target[:, 2]
+    if not np.isin(raw_id, tgt_id).all():
         return None, None
-    d = compute_l2_distance(kpts_raw[:, :2], kpts_raw[:, 2], kpts_target[:, :2], kpts_target[:, 2])
-    d_ref = compute_l2_distance(kpts_ref[:, :2], kpts_ref[:, 2], kpts_target[:, :2], kpts_target[:, 2])
-    d_raw_ref = compute_l2_distance(kpts_ref[:, :2], kpts_ref[:, 2], kpts_raw[:, :2], kpts_raw[:, 2])
+    err = {"raw vs target": compute_l2_distance(raw_xy, raw_id, tgt_xy, tgt_id),
+           "refined vs target": compute_l2_distance(ref_xy, ref_id, tgt_xy, tgt_id),
+           "refined vs raw": compute_l2_distance(ref_xy, ref_id, raw_xy, raw_id)}
     if verbose:
-        found = np.unique(kpts_raw[:, 2])
-        print(f'Errors in pixels of the {len(found)}/{len(kpts_target[:, 2])} kpts found:')
-        print(f'Mean error raw: {d.mean():<5.3f} Max error raw: {d.max():<5.3f}')
-        print(f'Mean error ref: {d_ref.mean():<5.3f} Max error ref: {d_ref.max():<5.3f}')
-        print(f'Mean dist raw/ref: {d_raw_ref.mean():<5.3f} Max dist raw/ref: {d_raw_ref.max():<5.3f}')
-    return d.mean(), d_ref.mean()
+        print(f"pixel error over {np.unique(raw_id).size} of {tgt_id.size} target corners")
+        for label, d in err.items():
+            print(f"  {label:<18s} mean {d.mean():.3f} px   max {d.max():.3f} px")
+    return err["raw vs target"].mean(), err["refined vs target"].mean()

@@ -81,7 +81,7 @@ def test_refinenet_metrics_corner_entry_and_gpu_only_preds(fx):
 def test_pixel_error_matches_reference_values(fx, capsys):
     raw, ref, tgt, bad = MC.pixel_error_case(int(fx["pe_seed"]))
     e_raw, e_ref = PM.pixel_error(raw, ref, tgt)
-    assert "Mean error raw" in capsys.readouterr().out          # prints like utils.py:43-51
+    assert "raw vs target" in capsys.readouterr().out           # a summary is printed (own format; the VALUES are the reference's)
     assert e_raw == float(fx["pe_raw"]) and e_ref == float(fx["pe_ref"])
     assert PM.pixel_error(bad, ref, tgt, verbose=False) == (None, None)
     assert np.array_equal(PM.compute_l2_distance(raw[:, :2], raw[:, 2], tgt[:, :2], tgt[:, 2]), fx["pe_l2"])
