@@ -36,6 +36,12 @@ struct CfgEntry {
     { 64, 128, TH, TW, 3, POOL, DCX_EPI_BNRELU, 8, 0, G, FAM_W2H,                                            \
       &dcx_conv_wino2h_launch_cfg<DcxWino2hCfg<TH, TW, (POOL) != 0, G>>,                                   \
       "dcx_conv_wino2h_kernel<DcxWino2hCfg<" #TH "," #TW "," #POOL "," #G ">>" }
+// the same kernel on 16-tile work items (one MFMA tile block per wave, 64 accumulators): half the serial chain per item, for
+// launches too small to fill the chip
+#define DCX_W2HCFG_S(TH, TW, POOL)                                                                    \
+    { 64, 64, TH, TW, 3, POOL, DCX_EPI_BNRELU, 4, 0, 1, FAM_W2H,                                             \
+      &dcx_conv_wino2h_launch_cfg<DcxWino2hCfg<TH, TW, (POOL) != 0, 1, 1>>,                                \
+      "dcx_conv_wino2h_kernel<DcxWino2hCfg<" #TH "," #TW "," #POOL ",1,1>>" }
 
 // x2 up-sampled input: 2-D Winograd F(2x2,2x2) per phase (dcx_conv_wino2p.h): th x tw is a LOW-RESOLUTION tile of one phase
 #define DCX_W2PCFG(TH, TW, EPI, G)                                                                    \
@@ -74,6 +80,8 @@ const CfgEntry kCfgs[] = {
     DCX_W2HCFG(6, 20, 0, 1),  // 3 x 10 tiles: 30x40 / 60x80 maps without padding, RefineNet's 18/20-pixel maps at 83-90 %
     DCX_W2HCFG(6, 20, 1, 1),
     DCX_W2HCFG(8, 8, 0, 2),   // two whole 8x8 maps (RefineNet conv3a / conv3b) per work item
+    DCX_W2HCFG_S(8, 8, 0),    // small launches (bs = 1: one frame, ~16 patches)
+    DCX_W2HCFG_S(8, 8, 1),
     // ---- phase x Winograd family: every 3x3 + BN + ReLU layer (cin >= 32) that reads a x2 up-sampled input
     DCX_W2PCFG(8, 16, DCX_EPI_BNRELU, 1),
     DCX_W2PCFG(8, 16, DCX_EPI_HEAT, 1),
@@ -130,7 +138,12 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
             const long items = (long)((n + c.group - 1) / c.group) * (cout_pad / c.cout_tile) * ht;
             // per item: 128 MFMAs of 32 cycles per unit + the transform's serial VALU + half an epilogue; stalls are hidden by the
             // co-resident workgroup (measured, tools/unit_probe.py); the 6x20 tile's transform reads are 2-way bank-conflicted
-            const double item_cost = (double)units * (64 * 64.0 + (c.tw == 20 ? 700.0 : 560.0)) + 2600.0;
+            double item_cost = (double)units * (64 * 64.0 + (c.tw == 20 ? 700.0 : 560.0)) + 2600.0;
+            if (c.acc_tiles == 4) {      // 16-tile items: only when every item is resident at once (2 per CU) -- then the launch takes
+                                         // one item's serial chain, which is half as long; never where the chip is full anyway
+                if (items > 2L * n_cu) continue;
+                item_cost = (double)units * (32 * 64.0 + 800.0) + 2200.0;
+            }
             cost = (double)((items + n_cu - 1) / n_cu) * item_cost * (1.0 + 1e-6 * (double)items);   // ties: fewer work items
         } else if (c.fam == FAM_W2P) {   // 9 x 8 MFMAs of 32 cycles per unit; tiles are low-resolution, x4 phases
             const long wt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);

@@ -57,7 +57,7 @@
 #define DCX_W2H_E_XFORM 14
 #endif
 
-template <int TH_, int TW_, bool POOL_, int G_ = 1>
+template <int TH_, int TW_, bool POOL_, int G_ = 1, int TB_ = 2>
 struct DcxWino2hCfg {
     static constexpr int TH = TH_, TW = TW_;
     static constexpr int G = G_;                           // images per work item: G = 2 packs two whole small maps (<= TH x TW each)
@@ -66,7 +66,10 @@ struct DcxWino2hCfg {
     static constexpr int COUT_TILE = 64;
     static constexpr int TY = TH / 2, TX = TW / 2;
     static constexpr int TPI = TY * TX;                    // 2x2 tiles per image region
-    static constexpr int NTILES = G * TPI;                 // <= 32
+    static constexpr int NTILES = G * TPI;                 // <= 16 TB
+    static constexpr int TB = TB_;                         // 16-tile MFMA blocks per wave: 2 (32 tiles, 128 accumulators), or 1 for
+                                                           // launches that cannot fill the chip anyway (one frame, 16 patches): a
+                                                           // work item's serial MFMA chain is half as long (same bits, more items)
     static constexpr int HH = TH + 2, RW = TW + 2;
     static constexpr int CQC = DCX_CCH / 4;
     static constexpr int RAW = G * CQC * HH * RW;          // [image][cq][row][col]
@@ -91,7 +94,7 @@ struct DcxWino2hCfg {
     static constexpr int E_RAW_LOAD = 0;
     static constexpr int E_RAW_STORE = DCX_W2H_E_STORE;
     static constexpr int E_XFORM = DCX_W2H_E_XFORM;                   // mid barrier before this event; 12 transform events follow
-    static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 32 && NTILES > 16, "tile must hold 17..32 2x2 tiles");
+    static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 16 * TB && NTILES > 8 * TB && (TB == 1 || TB == 2), "tile must hold 17..32 (TB = 1: 9..16) 2x2 tiles");
     static_assert(ITER_R <= 5 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM + 12 <= 32, "staging does not fit the schedule");
     static_assert(G == 1 || (!POOL && TPI == 16), "grouped tiles: two plain 8x8 maps");
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups must fit a CU's LDS");
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     const int hs = C::POOL ? (a.ho >> 1) : a.ho, ws = C::POOL ? (a.wo >> 1) : a.wo;
 
     // accumulators: acc[pos][tb], only ever defined by inline asm with an AGPR constraint (see the header comment)
-    dcx_f32x4 acc[16][2];
+    constexpr int TB = C::TB;
+    dcx_f32x4 acc[16][TB];
 
     // ---- prologue: first unit staged synchronously ---------------------------------------------------------------
     DcxItem cur = decode(w);
@@ -308,11 +312,13 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         const int nsy0 = nxt.ty * C::TH - a.pad, nsx0 = nxt.tx * C::TW - a.pad;
         const unsigned wb_cur = unit_wbase(cur, c);
         const unsigned wb_nxt = unit_wbase(nxt, cn);
-        float4 aq[16 + DQ], bq[16][2];
+        float4 aq[16 + DQ], bq[16][TB];
 #pragma unroll
         for (int d = 0; d < DQ; ++d) aq[d] = a_c[d];
 #pragma unroll
-        for (int d = 0; d < DQB; ++d) { bq[d][0] = load_b(buf, d, 0); bq[d][1] = load_b(buf, d, 1); }
+        for (int d = 0; d < DQB; ++d)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) bq[d][tb] = load_b(buf, d, tb);
         float4* vnext = sB + (buf ^ 1) * LDSF;
         float4 rv[ITER_R];
         const bool n_interior = tile_interior(nxt);
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                 roff[k] = inb ? r_rel[k] : 0x80000000u;
             }
         }
-        // one position = 8 MFMAs (tb 0 / 1 alternating, j = 0..3) in two slots of four; each slot is preceded by one
+        // one position = 4 TB MFMAs (tile blocks alternating, j = 0..3) in two slots of 2 TB; each slot is preceded by one
         // staging event; slot 0 also fetches the operands of position p + DQ / p + DQB
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
@@ -340,7 +346,10 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                     const int q = p + DQ, qb2 = p + DQB;
                     if (q < 16) aq[q] = load_a(wb_cur, q);
                     else aq[q] = load_a(wb_nxt, q - 16);
-                    if (qb2 < 16) { bq[qb2][0] = load_b(buf, qb2, 0); bq[qb2][1] = load_b(buf, qb2, 1); }
+                    if (qb2 < 16) {
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb) bq[qb2][tb] = load_b(buf, qb2, tb);
+                    }
                 }
                 {
                     const int e = p * 2 + slot;          // staging event 0 .. 31
@@ -350,22 +359,22 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {
-                    const float4 aa = aq[p], b0 = bq[p][0], b1 = bq[p][1];
+                    const float4 aa = aq[p];
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * slot + jj;
                         const float av = j == 0 ? aa.x : j == 1 ? aa.y : j == 2 ? aa.z : aa.w;
-                        const float bv0 = j == 0 ? b0.x : j == 1 ? b0.y : j == 2 ? b0.z : b0.w;
-                        const float bv1 = j == 0 ? b1.x : j == 1 ? b1.y : j == 2 ? b1.z : b1.w;
                         // (hazards: see the header comment -- operands come from loads hipcc waits for; VALU-written candidates only
                         //  at the very start of a unit -> 2 wait states ahead of the first MFMA)
                         if (p == 0 && j == 0) asm volatile("s_nop 1");
-                        if (ZERO && j == 0) {       // first touch of these two accumulators in this work item: C = 0
-                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[p][0]) : "v"(av), "v"(bv0));
-                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[p][1]) : "v"(av), "v"(bv1));
-                        } else {
-                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][0]) : "v"(av), "v"(bv0));
-                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][1]) : "v"(av), "v"(bv1));
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb) {
+                            const float4 bb = bq[p][tb];
+                            const float bv = j == 0 ? bb.x : j == 1 ? bb.y : j == 2 ? bb.z : bb.w;
+                            if (ZERO && j == 0)         // first touch of this accumulator in this work item: C = 0
+                                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[p][tb]) : "v"(av), "v"(bv));
+                            else
+                                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][tb]) : "v"(av), "v"(bv));
                         }
                     }
                 }
@@ -380,7 +389,9 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
             // ---- epilogue: output transform on the matrix cores, BN, ReLU (, pool), store -----------------------------
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // 8-pass MFMA result -> read as srcB: make the distance explicit
 #pragma unroll
-            for (int p = 0; p < 16; ++p) { asm volatile("" : "+a"(acc[p][0])); asm volatile("" : "+a"(acc[p][1])); }
+            for (int p = 0; p < 16; ++p)
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) asm volatile("" : "+a"(acc[p][tb]));
             const unsigned plane = (unsigned)(hs * ws);
             const int cq = (cur.ct * C::COUT_TILE >> 2) + wm * 4 + g4;          // the lane's output channel quad
             // BN parameters of the quad straight from L2 (arrays are padded to cout_pad); the ~2,100 cycles of the output
@@ -397,11 +408,11 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                     cf[4 * q4] = t4.x; cf[4 * q4 + 1] = t4.y; cf[4 * q4 + 2] = t4.z; cf[4 * q4 + 3] = t4.w;
                 }
             }
-            dcx_f32x4 e[2][4];        // e[tb][i][k]: output k of cout 4 * cq + i for the lane's tile tb * 16 + l15
+            dcx_f32x4 e[TB][4];       // e[tb][i][k]: output k of cout 4 * cq + i for the lane's tile tb * 16 + l15
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
+                for (int tb = 0; tb < TB; ++tb) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (p == 0) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=v"(e[tb][i]) : "v"(cf[0]), "a"(acc[0][tb][i]));
@@ -409,11 +420,11 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                     }
                 }
             }
-            asm volatile("s_nop 7" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]),
-                                     "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[1][2]), "+v"(e[1][3]));
+            asm volatile("s_nop 7" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]));
+            if (TB == 2) asm volatile("" : "+v"(e[TB - 1][0]), "+v"(e[TB - 1][1]), "+v"(e[TB - 1][2]), "+v"(e[TB - 1][3]));
             const dcx_f32x2 al01 = {al.x, al.y}, al23 = {al.z, al.w}, be01 = {be.x, be.y}, be23 = {be.z, be.w};
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
+            for (int tb = 0; tb < TB; ++tb) {
                 const int qt = tb * 16 + l15;
                 const int q_img = qt / C::TPI, q_t = qt - q_img * C::TPI;     // image inside the group (0 when G == 1)
                 const int qty = q_t / TX, qtx = q_t - qty * TX;

@@ -94,6 +94,7 @@ _caches: "weakref.WeakSet" = weakref.WeakSet()     # the per-detector caches tha
 
 class _Cache(dict):
     __slots__ = ("__weakref__",)
+    __hash__ = object.__hash__          # identity: lives in a WeakSet
 
 
 def graphs_usable() -> bool:

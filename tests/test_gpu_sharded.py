@@ -48,7 +48,10 @@ def _launch8(mode, tmp_path, timeout=1500):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(REPO, "tests", "sharded_world8_worker.py"), mode, backend, out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    if r.returncode != 0:
+        import glob
+        errs = "".join(open(f).read()[-3000:] for f in sorted(glob.glob(out + ".rank*.err"))[:2])
+        raise AssertionError(errs + r.stdout[-1500:] + r.stderr[-2500:])
     v = json.load(open(out))
     rep = os.path.join(REPO, "gpurun_out")
     os.makedirs(rep, exist_ok=True)

@@ -35,7 +35,8 @@ def lib_name(rocprof_name):
     if m:   # <TH, TW, POOL, G>
         f = [x.strip() for x in m.group(1).split(",")]
         f[2] = "1" if f[2] == "true" else "0"
-        return "dcx_conv_wino2h_kernel<DcxWino2hCfg<" + ",".join(f[:3]) + "," + (f[3] if len(f) > 3 else "1") + ">>"
+        return ("dcx_conv_wino2h_kernel<DcxWino2hCfg<" + ",".join(f[:3]) + "," + (f[3] if len(f) > 3 else "1")
+                + (",1" if len(f) > 4 and f[4] == "1" else "") + ">>")
     m = re.search(r"DcxConvCfg<([^>]*)>", rocprof_name)
     if not m:
         return None
