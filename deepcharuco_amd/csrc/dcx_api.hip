@@ -482,22 +482,24 @@ namespace {
 // n_hint: how many of the max_patches slots are expected to be live (0: unknown).  The launches are sized for the capacity
 // and skip dead patches through d_total on the device; the hint only steers the tile cost model (at bs=1 the capacity is 64
 // slots but ~16 corners fire: tiles chosen for 64 patches run a 4x longer serial chain per workgroup than needed).
-int refiner_run(const dcx_refiner* rf, const float* d_patches, int max_patches, int n_hint, const int32_t* d_total,
-                const int32_t* d_table, void* d_ws, size_t ws_bytes, int32_t* d_corners, float* d_xy, float* d_heat,
-                void* stream);
+struct FrameSrc { const uint8_t* frames; long frame_stride; int pitch, height, width; };   // pipeline: patches come out of the frames
+int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* fsrc, int max_patches, int n_hint,
+                const int32_t* d_total, const int32_t* d_table, void* d_ws, size_t ws_bytes, int32_t* d_corners, float* d_xy,
+                float* d_heat, void* stream);
 }  // namespace
 
 extern "C" int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches, int max_patches,
                                    const int32_t* d_total, const int32_t* d_table, void* d_ws, size_t ws_bytes,
                                    int32_t* d_corners, float* d_xy, float* d_heat, void* stream) {
-    return refiner_run(rf, d_patches, max_patches, 0, d_total, d_table, d_ws, ws_bytes, d_corners, d_xy, d_heat, stream);
+    return refiner_run(rf, d_patches, nullptr, max_patches, 0, d_total, d_table, d_ws, ws_bytes, d_corners, d_xy, d_heat, stream);
 }
 
 namespace {
-int refiner_run(const dcx_refiner* rf, const float* d_patches, int max_patches, int n_hint, const int32_t* d_total,
-                const int32_t* d_table, void* d_ws, size_t ws_bytes, int32_t* d_corners, float* d_xy, float* d_heat,
-                void* stream) {
-    if (!rf || !d_patches || !d_ws) return DCX_E_ARG;
+int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* fsrc, int max_patches, int n_hint,
+                const int32_t* d_total, const int32_t* d_table, void* d_ws, size_t ws_bytes, int32_t* d_corners, float* d_xy,
+                float* d_heat, void* stream) {
+    if (!rf || !d_ws || ((d_patches == nullptr) == (fsrc == nullptr))) return DCX_E_ARG;
+    if (fsrc != nullptr && (d_total == nullptr || d_table == nullptr)) return DCX_E_ARG;
     if (d_xy != nullptr && d_table == nullptr) return DCX_E_ARG;
     if (max_patches <= 0 || max_patches > (1 << 22)) return DCX_E_SHAPE;
     const RefWs L = ref_layout(max_patches);
@@ -508,9 +510,12 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, int max_patches, 
     float* buf1 = (float*)(ws + L.buf1);
     const int p = max_patches;
     const int* lim = d_total;
-    // conv1a (pad 0) 24 -> 22 (refinenet.py:56)
-    int rc = dcx_launch_conv1_f32(d_patches, 576, 24, p, 24, 24, 0, rf->first.w, rf->first.bias, rf->first.alpha,
-                                  rf->first.beta, buf0, lim, s);
+    // conv1a (pad 0) 24 -> 22 (refinenet.py:56); in the pipeline fused with extract_patches (model_utils.py:19-36)
+    int rc = fsrc != nullptr
+        ? dcx_launch_conv1_patches_u8(fsrc->frames, fsrc->frame_stride, fsrc->pitch, fsrc->height, fsrc->width, d_table, d_total, p,
+                                      rf->first.w, rf->first.bias, rf->first.alpha, rf->first.beta, buf0, s)
+        : dcx_launch_conv1_f32(d_patches, 576, 24, p, 24, 24, 0, rf->first.w, rf->first.bias, rf->first.alpha,
+                               rf->first.beta, buf0, lim, s);
     if (rc) return rc;
     // refinenet.py:57-78: {layer, input size, ups-on-read, pad, pool}
     struct Step { int layer, hin, ups, pad, pool; };
@@ -552,7 +557,7 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, int max_patches, 
 
 // ---- whole pipeline -----------------------------------------------------------------------------
 namespace {
-struct PipeWs { size_t det, table, total_i, patches, ref, total; };
+struct PipeWs { size_t det, table, total_i, ref, total; };
 PipeWs pipe_layout(const dcx_detector* det, const dcx_refiner* rf, int b, int h, int w, int kmax) {
     PipeWs L;
     const size_t p = (size_t)b * kmax;
@@ -560,7 +565,6 @@ PipeWs pipe_layout(const dcx_detector* det, const dcx_refiner* rf, int b, int h,
     L.det = off; off = align_up(off + det_layout(det->n_ids, b, h, w).total, 256);
     L.table = off; off = align_up(off + p * 16, 256);
     L.total_i = off; off = align_up(off + 256, 256);
-    L.patches = off; off = align_up(off + (rf ? p * 576 * 4 : 0), 256);
     L.ref = off; off = align_up(off + (rf ? ref_layout((int)p).total : 0), 256);
     L.total = off;
     return L;
@@ -594,27 +598,29 @@ int infer_range(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d
         const int hc = height / 8, wc = width / 8;
         const float* act = (const float*)(ws + L.det + D.buf0);
         int32_t* codes = (int32_t*)(ws + L.det + D.codes);
+        // total_i: [0] = live patches of the batch, [1] = ticket of the compaction kernel (cleared by the tail kernel)
+        int32_t* total = (int32_t*)(ws + L.total_i);
         rc = dcx_launch_tail(act, batch, hc * wc, det->head_loc.w, det->head_loc.bias, det->head_ids.w, det->head_ids.bias,
-                             det->head_ids.cout_pad, det->n_ids + 1, dust_bin, codes, nullptr, nullptr, s);
+                             det->head_ids.cout_pad, det->n_ids + 1, dust_bin, codes, nullptr, nullptr, rf ? total + 1 : nullptr, s);
         if (rc) return rc;
-        rc = dcx_launch_compact(codes, batch, hc, wc, dust_bin, kmax, d_counts, d_rows, s);
+        if (rf == nullptr) {
+            rc = dcx_launch_compact(codes, batch, hc, wc, dust_bin, kmax, d_counts, d_rows, s);
+            if (rc) return rc;
+            if (timing && (rc = timing_mark(2, s))) return rc;
+            return timing ? timing_mark(3, s) : 0;
+        }
+        // ordered compaction per frame + (last workgroup) the patch table of the batch: one launch
+        rc = dcx_launch_compact_table(codes, batch, hc, wc, dust_bin, kmax, d_counts, d_rows, (int32_t*)(ws + L.table), total,
+                                      total + 1, s);
         if (rc) return rc;
-    }
-    if (rf == nullptr) {
-        if (timing && (rc = timing_mark(2, s))) return rc;
-        return timing ? timing_mark(3, s) : 0;
     }
     int32_t* table = (int32_t*)(ws + L.table);
     int32_t* total = (int32_t*)(ws + L.total_i);
     const int p = batch * kmax;
-    rc = dcx_build_patch_table(d_counts, d_rows, batch, kmax, table, total, stream);
-    if (rc) return rc;
-    rc = dcx_extract_patches_u8(d_frames_u8, frame_stride, pitch, height, width, table, total, p,
-                                (float*)(ws + L.patches), stream);
-    if (rc) return rc;
     if (timing && (rc = timing_mark(2, s))) return rc;
     // expected live patches: a board has n_ids corners, so ~n_ids fire per frame (the capacity kmax is usually larger)
-    rc = refiner_run(rf, (const float*)(ws + L.patches), p, batch * (kmax < det->n_ids ? kmax : det->n_ids), total, table,
+    const FrameSrc src{d_frames_u8, frame_stride, pitch, height, width};       // RefineNet's conv1a gathers its 24x24 patches itself
+    rc = refiner_run(rf, nullptr, &src, p, batch * (kmax < det->n_ids ? kmax : det->n_ids), total, table,
                      ws + L.ref, L.total - L.ref, nullptr, d_xy, nullptr, stream);
     if (rc) return rc;
     return timing ? timing_mark(3, s) : 0;

@@ -56,6 +56,9 @@ struct DcxConvArgs {
     int cout_real;         // un-padded output channels (profiling only)
     int tiles_x, tiles_y;
     int xcd_walk;          // set by the launcher: XCD-aware item walk
+    int old_share;         // set by the launcher (with xcd_walk): permille of an XCD's items that go to the workgroups dispatched FIRST
+                           // (the older of the two co-resident workgroups of a CU gets the matrix pipe first and works faster);
+                           // 0 = even split
 };
 
 // Picks a tile configuration for (ho, wo, cout_pad, pool, epi, ks) and launches.
@@ -63,6 +66,7 @@ struct DcxConvArgs {
 int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t stream);
 // Rounds cout up to what dcx_launch_conv_mfma needs for cout_pad.
 int dcx_conv_cout_pad(int cout);
+int dcx_old_share();       // permille (DCX_OLD_SHARE, tuning knob; see DcxConvArgs::old_share)
 // Number of partial arg-max slots per image the DCX_EPI_HEAT launch will write for an (ho, wo) heat-map (size of part_*);
 // ups: the layer reads its input through a x2 up-sampling (the phase variant then writes 4 slots per low-resolution tile).
 int dcx_conv_heat_tiles(int ho, int wo, int ups);
@@ -88,10 +92,20 @@ int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, 
 // fused detector tail (dcx_tail.hip): 1x1 heads + per-cell arg-max + dust-bin rule -> packed codes (loc | id << 8)
 int dcx_launch_tail(const float* act_c4_512, int batch, int cells, const float* w_loc, const float* b_loc,
                     const float* w_ids, const float* b_ids, int ids_cout_pad, int n_ids1, int dust_bin,
-                    int32_t* codes, int32_t* loc_argmax, int32_t* ids_argmax, hipStream_t s);
+                    int32_t* codes, int32_t* loc_argmax, int32_t* ids_argmax, int32_t* zero_word, hipStream_t s);
+                    // zero_word (nullable): an int32 the kernel clears -- the ticket of the dcx_launch_compact_table that follows
 // ordered compaction of packed codes into per-frame rows (dcx_misc.hip)
 int dcx_launch_compact(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
                        int32_t* rows, hipStream_t s);
+// the same compaction + (last workgroup to finish) the patch table of the whole batch: exclusive scan of min(counts, kmax),
+// table[slot] = (frame, x, y, frame * kmax + k), *total = live patches.  *ticket must be 0 at entry (it is left 0).
+int dcx_launch_compact_table(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
+                             int32_t* rows, int32_t* table, int32_t* total, int32_t* ticket, hipStream_t s);
+// RefineNet conv1a (pad 0, 24x24 -> 22x22) reading its patches straight out of the u8 frames through the patch table
+// (extract_patches + pre_bgr_image + conv1a in one kernel: the patch tensor is never materialised)
+int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int h, int w, const int32_t* table,
+                                const int* total, int max_patches, const float* w9x64, const float* bias,
+                                const float* alpha, const float* beta, float* out_c4, hipStream_t s);
 int dcx_launch_refine_finalize(const float* part_val, const int* part_idx, int tiles, int wo,
                                int max_patches, const int* total, const int32_t* table,
                                int32_t* corners, float* xy, hipStream_t s);

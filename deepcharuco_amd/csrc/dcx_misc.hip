@@ -76,6 +76,78 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ 
     }
 }
 
+// RefineNet conv1a for the pipeline: output pixel (oy, ox) of patch p reads patch pixels (oy + dy, ox + dx), i.e. image pixels
+// (y - 12 + oy + dy, x - 12 + ox + dx) of frame table[p].x around key-point (x, y) = table[p].(y, z), zero outside the image
+// (model_utils.py:19-36 pads the NORMALISED image with 0) -- the values dcx_gather_kernel would have written, the arithmetic of
+// dcx_conv1_kernel (taps 0..8 dy-major, + bias, BN affine, ReLU): bit-identical to gather + conv1a.
+__global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* __restrict__ frames, long frame_stride, int pitch,
+                                                                  int h, int w, const int32_t* __restrict__ table,
+                                                                  const int* __restrict__ total, int max_patches,
+                                                                  const float* __restrict__ w9x64, const float* __restrict__ bias,
+                                                                  const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                                  float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
+    const int n_end = min(max_patches, *total);
+    if ((int)blockIdx.y >= n_end) return;
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) sw[i] = w9x64[i];
+    if (threadIdx.x < 64) {
+        sw[576 + threadIdx.x] = bias[threadIdx.x];
+        sw[640 + threadIdx.x] = alpha[threadIdx.x];
+        sw[704 + threadIdx.x] = beta[threadIdx.x];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= 22 * 22) return;
+    const int oy = p / 22, ox = p - oy * 22;
+    const float4* sw4 = reinterpret_cast<const float4*>(sw);
+    float4* out4 = reinterpret_cast<float4*>(out);
+    for (int n = blockIdx.y; n < n_end; n += gridDim.y) {     // gridDim.y is capped at 65535 patches
+        const int4 t = reinterpret_cast<const int4*>(table)[n];
+        const uint8_t* img = frames + (size_t)t.x * frame_stride;
+        float x[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iy = t.z - 12 + oy + dy, ix = t.y - 12 + ox + dx;
+                const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+                const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
+                const float v = dcx_norm_u8(img[(size_t)cy * pitch + cx]);
+                x[dy * 3 + dx] = inb ? v : 0.0f;
+            }
+#pragma unroll 4
+        for (int cq = 0; cq < 16; ++cq) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const float4 wv = sw4[tp * 16 + cq];
+                acc.x = fmaf(wv.x, x[tp], acc.x);
+                acc.y = fmaf(wv.y, x[tp], acc.y);
+                acc.z = fmaf(wv.z, x[tp], acc.z);
+                acc.w = fmaf(wv.w, x[tp], acc.w);
+            }
+            const float4 bi = sw4[144 + cq], al = sw4[160 + cq], be = sw4[176 + cq];
+            float4 y;
+            y.x = fmaxf(fmaf(acc.x + bi.x, al.x, be.x), 0.f);
+            y.y = fmaxf(fmaf(acc.y + bi.y, al.y, be.y), 0.f);
+            y.z = fmaxf(fmaf(acc.z + bi.z, al.z, be.z), 0.f);
+            y.w = fmaxf(fmaf(acc.w + bi.w, al.w, be.w), 0.f);
+            out4[((size_t)n * 16 + cq) * (size_t)(22 * 22) + p] = y;
+        }
+    }
+}
+
+int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int h, int w, const int32_t* table,
+                                const int* total, int max_patches, const float* w9x64, const float* bias,
+                                const float* alpha, const float* beta, float* out_c4, hipStream_t s) {
+    if (!frames || !table || !total || !w9x64 || !bias || !alpha || !beta || !out_c4) return DCX_E_ARG;
+    if (max_patches <= 0 || h <= 0 || w <= 0) return DCX_E_SHAPE;
+    dim3 grid(2, (unsigned)(max_patches < 65535 ? max_patches : 65535));
+    hipLaunchKernelGGL(dcx_conv1_patches_kernel, grid, dim3(256), 0, s, frames, frame_stride, pitch, h, w, table, total,
+                       max_patches, w9x64, bias, alpha, beta, out_c4);
+    return (int)hipGetLastError();
+}
+
 template <typename TIn>
 static int launch_conv1(const TIn* in, long image_stride, int pitch, int n, int h, int w, int pad,
                         const float* w9x64, const float* bias, const float* alpha, const float* beta,
@@ -302,14 +374,11 @@ extern "C" int dcx_pred_to_keypoints(const float* d_loc, const float* d_ids, int
 
 // ---------------------------------------------------------------------------------------
 // patch table: exclusive scan of min(counts, kmax) over the frames of a batch (one workgroup).
-__global__ __launch_bounds__(256) void dcx_patch_table_kernel(const int32_t* __restrict__ counts,
-                                                                const int32_t* __restrict__ rows, int batch, int kmax,
-                                                                int32_t* __restrict__ table, int32_t* __restrict__ total) {
-    __shared__ int s_cnt[256], s_start[256];
-    __shared__ int wave_tot[4];
-    __shared__ int carry;
+__device__ __forceinline__ void dcx_patch_table_body(const int32_t* __restrict__ counts, const int32_t* __restrict__ rows,
+                                                     int batch, int kmax, int32_t* __restrict__ table, int32_t* __restrict__ total,
+                                                     int* s_cnt, int* s_start, int* wave_tot, int* carry) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
+    if (tid == 0) *carry = 0;
     __syncthreads();
     for (int b0 = 0; b0 < batch; b0 += 256) {
         const int b = b0 + tid;
@@ -323,7 +392,7 @@ __global__ __launch_bounds__(256) void dcx_patch_table_kernel(const int32_t* __r
         }
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
-        int off = carry;
+        int off = *carry;
         for (int w = 0; w < wave; ++w) off += wave_tot[w];
         s_cnt[tid] = c;
         s_start[tid] = off + incl - c;
@@ -339,10 +408,69 @@ __global__ __launch_bounds__(256) void dcx_patch_table_kernel(const int32_t* __r
             }
         }
         __syncthreads();
-        if (tid == 0) carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        if (tid == 0) *carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         __syncthreads();
     }
-    if (tid == 0) *total = carry;
+    if (tid == 0) *total = *carry;
+}
+
+__global__ __launch_bounds__(256) void dcx_patch_table_kernel(const int32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ rows, int batch, int kmax,
+                                                                int32_t* __restrict__ table, int32_t* __restrict__ total) {
+    __shared__ int s_cnt[256], s_start[256];
+    __shared__ int wave_tot[4];
+    __shared__ int carry;
+    dcx_patch_table_body(counts, rows, batch, kmax, table, total, s_cnt, s_start, wave_tot, &carry);
+}
+
+// Pipeline path: per-frame ordered compaction (one workgroup per frame) AND, in the workgroup that finishes last, the patch
+// table of the whole batch -- two launches in one ("last block" pattern: every thread publishes its rows with a device-scope
+// fence, one thread takes a ticket; the workgroup that draws the last ticket sees all counts / rows after its own fence).
+__global__ __launch_bounds__(256) void dcx_compact_table_kernel(const int32_t* __restrict__ codes, int hc, int wc, int dust_bin,
+                                                                  int kmax, int32_t* __restrict__ counts, int32_t* __restrict__ rows,
+                                                                  int batch, int32_t* __restrict__ table, int32_t* __restrict__ total,
+                                                                  int32_t* __restrict__ ticket) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
+    __shared__ int s_last;
+    __shared__ int s_cnt[256], s_start[256];
+    __shared__ int wave_tot[4];
+    __shared__ int carry;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int cells = hc * wc;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < cells; c0 += 256) {
+        const int cell = c0 + tid;
+        bool fire = false;
+        int la = 0, ia = 0;
+        if (cell < cells) {
+            const int code = codes[(size_t)b * cells + cell];
+            la = code & 255; ia = code >> 8;
+            fire = ia != dust_bin;
+        }
+        dcx_compact_chunk(fire, la, ia, cell, wc, kmax, b, wave_cnt, &base_s, rows);
+    }
+    if (tid == 0) counts[b] = base_s;
+    __threadfence();                     // this thread's rows (and counts[b]) are visible device-wide ...
+    __syncthreads();                     // ... for every thread of the workgroup, before the ticket is drawn
+    if (tid == 0) s_last = atomicAdd(ticket, 1) == batch - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                     // acquire: the other workgroups' counts / rows
+    dcx_patch_table_body(counts, rows, batch, kmax, table, total, s_cnt, s_start, wave_tot, &carry);
+    if (tid == 0) *ticket = 0;           // leave the ticket ready for the next launch
+}
+
+int dcx_launch_compact_table(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
+                             int32_t* rows, int32_t* table, int32_t* total, int32_t* ticket, hipStream_t s) {
+    if (!codes || !counts || !rows || !table || !total || !ticket) return DCX_E_ARG;
+    if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0) return DCX_E_SHAPE;
+    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
+    hipLaunchKernelGGL(dcx_compact_table_kernel, dim3((unsigned)batch), dim3(256), 0, s, codes, hc, wc, dust_bin, kmax, counts,
+                       rows, batch, table, total, ticket);
+    return (int)hipGetLastError();
 }
 
 extern "C" int dcx_build_patch_table(const int32_t* d_counts, const int32_t* d_rows, int batch, int kmax,

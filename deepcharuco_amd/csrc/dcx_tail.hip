@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
                                                         const float4* __restrict__ w_ids, const float* __restrict__ b_ids,
                                                         int ids_cout_pad, int n_ids1, int tiles_per_frame, int dust_bin,
                                                         int32_t* __restrict__ codes, int32_t* __restrict__ loc_argmax,
-                                                        int32_t* __restrict__ ids_argmax) {
+                                                        int32_t* __restrict__ ids_argmax, int32_t* __restrict__ zero_word) {
     constexpr int NPIX = 32 * NT;
+    if (zero_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;     // ticket of the compaction kernel that follows
     __shared__ float red_v[4 + 1][NPIX];     // [job: loc tile 0..2, ids tile 0..1][pixel]
     __shared__ int red_i[4 + 1][NPIX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
 // act: C4 [B][act_cq_total = 128][cells][4] (convPa|convDa output); w_*: packed [cin/4 = 64][cout_pad][4]; codes [B][cells].
 int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, const float* b_loc, const float* w_ids,
                     const float* b_ids, int ids_cout_pad, int n_ids1, int dust_bin, int32_t* codes, int32_t* loc_argmax,
-                    int32_t* ids_argmax, hipStream_t s) {
+                    int32_t* ids_argmax, int32_t* zero_word, hipStream_t s) {
     if (!act || !w_loc || !b_loc || !w_ids || !b_ids || !codes) return DCX_E_ARG;
     if (batch <= 0 || cells <= 0 || n_ids1 < 2 || n_ids1 > 64 || ids_cout_pad < n_ids1) return DCX_E_SHAPE;
     if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
@@ -164,7 +165,7 @@ int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, 
     const float4* wi = reinterpret_cast<const float4*>(w_ids);
 #define DCX_TAIL_LAUNCH(NT, IT)                                                                                          \
     hipLaunchKernelGGL((dcx_tail_kernel<NT, IT>), dim3((unsigned)items), dim3(256), 0, s, a4, 128, cells, wl, b_loc, wi, b_ids, \
-                       ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax)
+                       ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax, zero_word)
     if (nt2) { if (two) DCX_TAIL_LAUNCH(2, 2); else DCX_TAIL_LAUNCH(2, 1); }
     else     { if (two) DCX_TAIL_LAUNCH(1, 2); else DCX_TAIL_LAUNCH(1, 1); }
 #undef DCX_TAIL_LAUNCH

@@ -7,11 +7,12 @@ H2D of the frame from pinned memory, BGR->gray on the device (``dcx_bgr2gray``),
 (``dcx_infer_batch``), D2H of the packed corner list -- into ONE hipGraph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm)
 and replays it per call: one launch from the host instead of ~30.  Results are those of ``infer_batch`` (same kernels,
 same order); a frame that fires more than ``kmax`` cells falls back to the eager path, which re-runs with a larger
-capacity.  A pipeline owns its pinned / device buffers and its stream, so ``run`` is serialised by a per-pipeline lock and
-``cached_pipeline`` hands every thread its own instance: concurrent ``infer_image`` callers on one model pair never share
-staging buffers.  The graph freezes the kernel choice made at capture time, so the cache key also carries the library's
-process-global mode (``dcx_get_deterministic``) and graphs are bypassed while per-stage timing / per-launch profiling is on
-(their hipEvents would be frozen into or out of the graph).
+capacity.  A pipeline owns its pinned / device buffers and its stream; capture and replay are serialised process-wide by one
+lock (``_graph_lock``): concurrent ``infer_image`` callers never share staging buffers mid-flight, and no hipGraph is captured
+while another thread replays one (capturing and replaying from several threads at once hung the HIP runtime in testing) --
+callers that want concurrency across threads use ``infer_batch_device`` on their own streams.  The graph freezes the kernel
+choice made at capture time, so the cache key also carries the library's process-global mode (``dcx_get_deterministic``) and
+graphs are bypassed while per-stage timing / per-launch profiling is on (their hipEvents would be frozen into or out of it).
 """
 from __future__ import annotations
 
@@ -55,12 +56,11 @@ class GraphedPipeline:
                     self._enqueue()
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            # thread_local: other threads may replay their own graphs / allocate while this one captures
+            # thread_local: other threads may allocate / launch eager work while this one captures
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 self._enqueue()
         self._in_np = self.pin_in.numpy()
         self._out_np = self.pin_out.numpy()
-        self._lock = threading.Lock()
 
     def _enqueue(self) -> None:
         self.dev_in.copy_(self.pin_in, non_blocking=True)
@@ -74,7 +74,7 @@ class GraphedPipeline:
         """frames: (B,H,W,3) BGR or (B,H,W) gray uint8 host array (as configured) -> list of B keypoint arrays."""
         if frames.shape != self._in_np.shape or frames.dtype != np.uint8:
             raise ValueError(f"expected uint8 frames of shape {self._in_np.shape}, got {frames.dtype} {frames.shape}")
-        with self._lock:                                      # the staging buffers belong to this pipeline: one run at a time
+        with _graph_lock:                                     # one capture / replay at a time per process
             np.copyto(self._in_np, frames)
             with torch.cuda.device(self.dev):
                 self.graph.replay()
@@ -88,7 +88,7 @@ class GraphedPipeline:
 
 _CACHE_MAX = 8        # per detector: graphs pin ~25 MB of workspace per 320x240 shape
 _cache_lock = threading.Lock()
-_capture_lock = threading.Lock()
+_graph_lock = threading.RLock()          # serialises hipGraph capture AND replay (+ the synchronise that follows) process-wide
 _caches: "weakref.WeakSet" = weakref.WeakSet()     # the per-detector caches that exist (for clear_graph_cache())
 
 
@@ -127,24 +127,24 @@ def drop_graphs_of_refiner(ref) -> None:
 
 def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int, bgr: bool,
                     kmax: int = DEFAULT_KMAX) -> Optional[GraphedPipeline]:
-    """One graph per (model pair, shape, library mode, calling thread) for ``infer_image``.  The cache lives ON the detector
+    """One graph per (model pair, shape, library mode) for ``infer_image``, shared by all threads.  The cache lives ON the detector
     object (a small LRU), so graphs die with the model instead of pinning it in a module-global table, and a re-allocated
     model can never alias a cached graph of a freed one."""
     det = deepc.model if hasattr(deepc, "model") else deepc
     ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
     key = (None if ref is None else (id(ref), ref.handle.value), dust_bin_ids, height, width, bgr, kmax,
-           int(_lib.lib().dcx_get_deterministic()), threading.get_ident())
-    with _cache_lock:
-        cache = getattr(det, "_graph_cache", None)
-        if cache is None:
-            cache = det._graph_cache = _Cache()
-            _caches.add(cache)
-        p = cache.pop(key, None)
-    if p is None:
-        with _capture_lock:                                   # one capture at a time per process
+           int(_lib.lib().dcx_get_deterministic()))
+    with _graph_lock:                                         # capture excludes every replay (and other captures)
+        with _cache_lock:
+            cache = getattr(det, "_graph_cache", None)
+            if cache is None:
+                cache = det._graph_cache = _Cache()
+                _caches.add(cache)
+            p = cache.pop(key, None)
+        if p is None:
             p = GraphedPipeline(dust_bin_ids, deepc, refinenet, 1, height, width, kmax, bgr)
-    with _cache_lock:
-        while len(cache) >= _CACHE_MAX:
-            cache.pop(next(iter(cache)))
-        cache[key] = p
+        with _cache_lock:
+            while len(cache) >= _CACHE_MAX:
+                cache.pop(next(iter(cache)))
+            cache[key] = p
     return p

@@ -716,62 +716,81 @@ def test_hipgraph_replay_equals_eager_launches(dev, golden_tiny):
         gp.run(imgs[2][None])
 
 
-def test_graph_cache_threads_modes_and_lifetime(dev, golden_tiny):
-    """(1) concurrent infer_image callers on one model pair get their own GraphedPipeline (no shared staging
-    buffers) and each returns ITS image's corners; (2) a mode switch (set_deterministic) drops the graphs captured under the
-    previous mode; (3) graphs are bypassed while timing is on; (4) the cache lives on the detector and dies with it."""
-    import gc
-    import threading
-    import weakref
-    import deepcharuco_amd.inference as I
-    from deepcharuco_amd import _lib, graph as G
-    dc, rn = _models(golden_tiny, dev)
-    t_dc, t_rn = O.to_torch_state_dict(golden_tiny.sd_dc), O.to_torch_state_dict(golden_tiny.sd_rn)
-    imgs = [np.repeat(W.synthetic_frames("noise", 50 + i, 1, 64, 96)[0][..., None], 3, axis=2) for i in range(4)]
-    exp = [O.infer_image(im, 16, t_dc, t_rn) for im in imgs]
-    assert len({e.tobytes() for e in exp}) == 4
-    out, errs = {}, []
-
-    def worker(i):
-        try:
-            for _ in range(25):
-                kp, _ = I.infer_image(imgs[i], 16, dc, rn, device="cuda")
-                if not (kp.shape == exp[i].shape and np.array_equal(kp, exp[i])):
-                    errs.append(i)
-            out[i] = threading.get_ident()
-        except Exception as e:      # noqa
-            errs.append(repr(e))
-    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    assert not errs and len(out) == 4
-    cache = dc.model._graph_cache
-    assert len({k[-1] for k in cache}) == 4                                  # one pipeline per calling thread
-    # (2) mode switch clears, and the next call captures under the new mode
-    I.set_deterministic(True)
+_GRAPH_CACHE_SCRIPT = r"""
+import gc, sys, threading, weakref
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests")
+import numpy as np, torch
+import deepcharuco_amd.inference as I
+from deepcharuco_amd import _lib, graph as G, weights as W
+from deepcharuco_amd.models.net import dcModel, lModel
+from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+from oracle import deepcharuco_oracle as O
+from conftest import GoldenCase
+case = GoldenCase("tiny_noise_64x96")
+dev = torch.device("cuda", 0)
+mk = lambda: (lModel(dcModel(case.n_ids, case.sd_dc, dev)), lRefineNet(RefineNet(case.sd_rn, dev)))
+dc, rn = mk()
+t_dc, t_rn = O.to_torch_state_dict(case.sd_dc), O.to_torch_state_dict(case.sd_rn)
+imgs = [np.repeat(W.synthetic_frames("noise", 50 + i, 1, 64, 96)[0][..., None], 3, axis=2) for i in range(4)]
+exp = [O.infer_image(im, 16, t_dc, t_rn) for im in imgs]
+assert len({{e.tobytes() for e in exp}}) == 4
+print("STEP oracle", flush=True)
+errs = []
+def worker(i):
     try:
-        assert len(cache) == 0
-        kp, _ = I.infer_image(imgs[0], 16, dc, rn, device="cuda")
-        assert np.array_equal(kp, exp[0]) and [k[-2] for k in cache] == [1]
-    finally:
-        I.set_deterministic(False)
+        for _ in range(25):
+            kp, _ = I.infer_image(imgs[i], 16, dc, rn, device="cuda")
+            if not (kp.shape == exp[i].shape and np.array_equal(kp, exp[i])):
+                errs.append(i)
+    except Exception as e:
+        errs.append(repr(e))
+ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errs, errs
+cache = dc.model._graph_cache
+assert len(cache) == 1                                  # one shared pipeline per (models, shape, mode); runs are serialised
+print("STEP threads", flush=True)
+I.set_deterministic(True)                               # (2) a mode switch drops the graphs captured under the previous mode
+try:
     assert len(cache) == 0
-    # (3) timing on -> eager launches, cache untouched
-    L = _lib.lib()
-    L.dcx_set_timing(1)
-    try:
-        assert not G.graphs_usable()
-        kp, _ = I.infer_image(imgs[1], 16, dc, rn, device="cuda")
-        assert np.array_equal(kp, exp[1]) and len(cache) == 0
-    finally:
-        L.dcx_set_timing(0)
-    # (4) lifetime: a model that ran graphed calls is freed when the caller drops it
-    dc2, rn2 = _models(golden_tiny, dev)
-    I.infer_image(imgs[2], 16, dc2, rn2, device="cuda")
-    ref = weakref.ref(dc2.model)
-    del dc2, rn2
-    gc.collect()
-    assert ref() is None
+    kp, _ = I.infer_image(imgs[0], 16, dc, rn, device="cuda")
+    assert np.array_equal(kp, exp[0]) and [k[-1] for k in cache] == [1]
+finally:
+    I.set_deterministic(False)
+assert len(cache) == 0
+print("STEP modes", flush=True)
+L = _lib.lib()                                          # (3) timing on -> eager launches, cache untouched
+L.dcx_set_timing(1)
+try:
+    assert not G.graphs_usable()
+    kp, _ = I.infer_image(imgs[1], 16, dc, rn, device="cuda")
+    assert np.array_equal(kp, exp[1]) and len(cache) == 0
+finally:
+    L.dcx_set_timing(0)
+print("STEP timing", flush=True)
+dc2, rn2 = mk()                                         # (4) a model that ran graphed calls is freed when the caller drops it
+I.infer_image(imgs[2], 16, dc2, rn2, device="cuda")
+ref = weakref.ref(dc2.model)
+del dc2, rn2
+gc.collect()
+assert ref() is None
+print("RESULT ok", flush=True)
+"""
+
+
+def test_graph_cache_threads_modes_and_lifetime(dev):
+    """(1) concurrent infer_image callers on one model pair are serialised around the shared GraphedPipeline (no
+    torn staging buffers) and each gets ITS image's corners; (2) a mode switch (set_deterministic) drops the graphs captured
+    under the previous mode; (3) graphs are bypassed while timing is on; (4) the cache lives on the detector and dies with it.
+    Runs in its own process under a hard timeout: a hang in the HIP runtime must fail this test, not stall the suite."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("DCX_FORCE_CFG", None)
+    out = subprocess.run([sys.executable, "-c", _GRAPH_CACHE_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True,
+                         timeout=240)
+    steps = [l for l in out.stdout.splitlines() if l.startswith(("STEP", "RESULT"))]
+    assert out.returncode == 0 and steps and steps[-1] == "RESULT ok", f"{steps}\n{out.stderr[-3000:]}"
 
 
 def test_default_mode_is_batch_invariant(dev):

@@ -38,7 +38,7 @@ def _launch(backend, world, tmp_path):
     return v
 
 
-def _launch8(mode, tmp_path, timeout=1500):
+def _launch8(mode, tmp_path, timeout=700):
     """Eight ranks; gloo on a 1-GPU box (the ranks time-slice the GPU), RCCL when eight GPUs are visible."""
     backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
     out = str(tmp_path / f"world8_{mode}.json")
