@@ -238,7 +238,9 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         L.dcx_profile_enable(0)
         if warm:
             dom_id = max(warm.items(), key=lambda kv: kv[1][1])[0]
-        L.dcx_profile_filter(dom_id)          # timed region: only the dominant kernel is bracketed
+        L.dcx_profile_filter(dom_id)          # timed region: only the dominant kernel is bracketed, and only every 5th of its
+        L.dcx_profile_sample(5)               # launches (a hipEvent bracket idles the GPU for ~11 us: 45 us per step if all four of
+                                              # a step were; 5 is coprime with the 4 launches per step, so every layer is sampled)
         L.dcx_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -266,6 +268,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         timed = fetch_profile(L, total_patches)
         L.dcx_profile_enable(0)
         L.dcx_profile_filter(-1)
+        L.dcx_profile_sample(1)
         L.dcx_profile_enable(1)
         extra_steps = 3
         for _ in range(extra_steps):

@@ -79,6 +79,7 @@ SIGNATURES = {
     "dcx_profile_enable": (_i, [_i]),
     "dcx_profile_count": (_i, []),
     "dcx_profile_filter": (_i, [_i]),
+    "dcx_profile_sample": (_i, [_i]),
     "dcx_profile_fetch": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_float), _i]),
     "dcx_profile_kernel_name": (C.c_char_p, [_i]),
     "dcx_profile_clocks": (_i, [C.POINTER(C.c_float), _i]),

@@ -172,6 +172,8 @@ constexpr int kClkSlots = 1024;
 constexpr int kClkWords = 64;   // per launch: 4 clock words + 3 timestamps per unit for the first 20 units
 bool g_prof = false;
 int g_prof_filter = -1;   // -1: record every launch; k: only launches of kernel id k
+int g_prof_every = 1;     // record every g_prof_every-th matching launch (each bracket costs ~11 us of idle GPU)
+long g_prof_seen = 0;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_used = 0;
@@ -208,6 +210,7 @@ extern "C" int dcx_profile_enable(int enabled) {
 }
 extern "C" int dcx_profile_enabled(void) { return g_prof ? 1 : 0; }
 extern "C" int dcx_profile_filter(int kernel_id) { g_prof_filter = kernel_id; return 0; }
+extern "C" int dcx_profile_sample(int every) { g_prof_every = every > 1 ? every : 1; g_prof_seen = 0; return 0; }
 extern "C" int dcx_profile_count(void) { return (int)g_recs.size(); }
 extern "C" const char* dcx_profile_kernel_name(int id) {
     const int n = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
@@ -308,6 +311,7 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
                              (a.ups == 1 && a.pad == 1 && ks == 3 && a.w_ups2w != nullptr) ? 1 : 0);
     if (c == nullptr) return DCX_E_SHAPE;
     if (!g_prof || (g_prof_filter >= 0 && g_prof_filter != (int)(c - kCfgs))) return c->launch(a, stream);
+    if (g_prof_every > 1 && (g_prof_seen++ % g_prof_every) != 0) return c->launch(a, stream);
     ProfRec r;
     r.kernel_id = (int)(c - kCfgs);
     r.n = a.n;

@@ -201,6 +201,9 @@ int dcx_profile_enabled(void);       /* 1 while per-launch profiling is on */
 int dcx_profile_count(void);
 /* restrict recording to one kernel id (-1 = all): keeps the event overhead out of a timed region */
 int dcx_profile_filter(int kernel_id);
+int dcx_profile_sample(int every);   /* bracket only every `every`-th matching launch (1 = all): the two hipEvent records of a
+                                        bracket keep the GPU idle for ~11 us, which a throughput measurement should not pay on
+                                        every launch */
 int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, double* flops_per_image, float* ms,
                       int max_records);
 const char* dcx_profile_kernel_name(int kernel_id);
