@@ -56,9 +56,6 @@ struct DcxConvArgs {
     int cout_real;         // un-padded output channels (profiling only)
     int tiles_x, tiles_y;
     int xcd_walk;          // set by the launcher: XCD-aware item walk
-    int old_share;         // set by the launcher (with xcd_walk): permille of an XCD's items that go to the workgroups dispatched FIRST
-                           // (the older of the two co-resident workgroups of a CU gets the matrix pipe first and works faster);
-                           // 0 = even split
 };
 
 // Picks a tile configuration for (ho, wo, cout_pad, pool, epi, ks) and launches.
@@ -66,7 +63,6 @@ struct DcxConvArgs {
 int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t stream);
 // Rounds cout up to what dcx_launch_conv_mfma needs for cout_pad.
 int dcx_conv_cout_pad(int cout);
-int dcx_old_share();       // permille (DCX_OLD_SHARE, tuning knob; see DcxConvArgs::old_share)
 // Number of partial arg-max slots per image the DCX_EPI_HEAT launch will write for an (ho, wo) heat-map (size of part_*);
 // ups: the layer reads its input through a x2 up-sampling (the phase variant then writes 4 slots per low-resolution tile).
 int dcx_conv_heat_tiles(int ho, int wo, int ups);

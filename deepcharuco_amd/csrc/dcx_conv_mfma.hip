@@ -281,12 +281,6 @@ int dcx_xcd_walk_enabled() {
     return v;
 }
 
-int dcx_old_share() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DCX_OLD_SHARE"); v = e ? atoi(e) : 0; if (v < 0 || v > 900) v = 0; }
-    return v;
-}
-
 int dcx_occupancy_override() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("DCX_OCC"); v = e ? atoi(e) : 0; }

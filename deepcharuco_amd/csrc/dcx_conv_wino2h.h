@@ -124,17 +124,6 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         w_end = (int)(((long)total * (x + 1)) >> 3);
         gstride = gridDim.x >> 3;
         w = lo + (blockIdx.x >> 3);
-        if (a.old_share > 0 && (gstride & 1) == 0) {
-            // The two workgroups of a CU are not served equally: the matrix pipe prefers the OLDER wave, so the workgroups
-            // dispatched first (slots < gstride / 2) finish an even share early and the last part of the launch runs at one
-            // workgroup per CU.  Static remedy: the older half walks the first old_share / 1000 of the XCD's items, the
-            // younger half the rest.
-            const int half = gstride >> 1, slot = blockIdx.x >> 3;
-            const int mid = lo + (int)(((long)(w_end - lo) * a.old_share) / 1000);
-            gstride = half;
-            if (slot < half) { w = lo + slot; w_end = mid; }
-            else { w = mid + (slot - half); }
-        }
     }
     if (w >= w_end) return;
     if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) {
@@ -519,7 +508,6 @@ static int dcx_conv_wino2h_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const long resident = (occ_env == 1 ? 1L : 2L) * dcx_device_cu_count();
     const long blocks = items < resident ? items : resident;
     a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
-    a.old_share = (a.xcd_walk && occ_env != 1 && items >= 4 * resident) ? dcx_old_share() : 0;
     static bool attr_set[DCX_MAX_DEVICES] = {};
     const int dev_i = dcx_current_device();
     if (!attr_set[dev_i]) {
