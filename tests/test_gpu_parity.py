@@ -20,8 +20,10 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_ATOL = 5e-5     # |logit| <= ~6
 XY_ATOL = 1e-4        # px, north-star tolerance (we get exact equality)
-MARGIN = 1e-5         # arg-max must match exactly wherever the reference's top-2 gap exceeds this (SURVEY.md H1 policy);
-                      # cells below it are COUNTED and their agreement reported in gpurun_out/parity_report.json
+MARGIN = 4e-5         # arg-max must match exactly wherever the reference's top-2 gap exceeds this: >= 2x the largest |HIP - oracle|
+                      # logit difference measured over 20,256 frames / 27 M arg-max decisions (1.81e-5, profiles/r03_stress_parity.txt:
+                      # 0 disagreements above 1e-5, 25 below it); cells under the margin are COUNTED and their agreement
+                      # reported in gpurun_out/parity_report.json (SURVEY.md H1 policy; rounds 1 / 2 used 1e-4 / 1e-5)
 
 REPORT = {}
 
