@@ -87,52 +87,57 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
                                                                   const float* __restrict__ alpha, const float* __restrict__ beta,
                                                                   float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
+    __shared__ float sp[24 * 24];                     // the normalised, zero-padded 24x24 patch (what extract_patches returns)
     const int n_end = min(max_patches, *total);
-    if ((int)blockIdx.y >= n_end) return;
-    for (int i = threadIdx.x; i < 9 * 64; i += 256) sw[i] = w9x64[i];
-    if (threadIdx.x < 64) {
-        sw[576 + threadIdx.x] = bias[threadIdx.x];
-        sw[640 + threadIdx.x] = alpha[threadIdx.x];
-        sw[704 + threadIdx.x] = beta[threadIdx.x];
+    if ((int)blockIdx.x >= n_end) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * 64; i += 256) sw[i] = w9x64[i];
+    if (tid < 64) {
+        sw[576 + tid] = bias[tid];
+        sw[640 + tid] = alpha[tid];
+        sw[704 + tid] = beta[tid];
     }
-    __syncthreads();
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= 22 * 22) return;
-    const int oy = p / 22, ox = p - oy * 22;
     const float4* sw4 = reinterpret_cast<const float4*>(sw);
     float4* out4 = reinterpret_cast<float4*>(out);
-    for (int n = blockIdx.y; n < n_end; n += gridDim.y) {     // gridDim.y is capped at 65535 patches
+    for (int n = blockIdx.x; n < n_end; n += gridDim.x) {     // one workgroup per patch (grid capped at 65535)
         const int4 t = reinterpret_cast<const int4*>(table)[n];
         const uint8_t* img = frames + (size_t)t.x * frame_stride;
-        float x[9];
+        __syncthreads();                                       // previous patch's readers are done with sp
+        for (int e = tid; e < 576; e += 256) {
+            const int i = e / 24, j = e - i * 24;
+            const int iy = t.z - 12 + i, ix = t.y - 12 + j;
+            const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+            const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
+            const float v = dcx_norm_u8(img[(size_t)cy * pitch + cx]);
+            sp[e] = inb ? v : 0.0f;
+        }
+        __syncthreads();
+        for (int p = tid; p < 22 * 22; p += 256) {
+            const int oy = p / 22, ox = p - oy * 22;
+            float x[9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int iy = t.z - 12 + oy + dy, ix = t.y - 12 + ox + dx;
-                const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
-                const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
-                const float v = dcx_norm_u8(img[(size_t)cy * pitch + cx]);
-                x[dy * 3 + dx] = inb ? v : 0.0f;
-            }
+                for (int dx = 0; dx < 3; ++dx) x[dy * 3 + dx] = sp[(oy + dy) * 24 + ox + dx];
 #pragma unroll 4
-        for (int cq = 0; cq < 16; ++cq) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int cq = 0; cq < 16; ++cq) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                const float4 wv = sw4[tp * 16 + cq];
-                acc.x = fmaf(wv.x, x[tp], acc.x);
-                acc.y = fmaf(wv.y, x[tp], acc.y);
-                acc.z = fmaf(wv.z, x[tp], acc.z);
-                acc.w = fmaf(wv.w, x[tp], acc.w);
+                for (int tp = 0; tp < 9; ++tp) {
+                    const float4 wv = sw4[tp * 16 + cq];
+                    acc.x = fmaf(wv.x, x[tp], acc.x);
+                    acc.y = fmaf(wv.y, x[tp], acc.y);
+                    acc.z = fmaf(wv.z, x[tp], acc.z);
+                    acc.w = fmaf(wv.w, x[tp], acc.w);
+                }
+                const float4 bi = sw4[144 + cq], al = sw4[160 + cq], be = sw4[176 + cq];
+                float4 y;
+                y.x = fmaxf(fmaf(acc.x + bi.x, al.x, be.x), 0.f);
+                y.y = fmaxf(fmaf(acc.y + bi.y, al.y, be.y), 0.f);
+                y.z = fmaxf(fmaf(acc.z + bi.z, al.z, be.z), 0.f);
+                y.w = fmaxf(fmaf(acc.w + bi.w, al.w, be.w), 0.f);
+                out4[((size_t)n * 16 + cq) * (size_t)(22 * 22) + p] = y;
             }
-            const float4 bi = sw4[144 + cq], al = sw4[160 + cq], be = sw4[176 + cq];
-            float4 y;
-            y.x = fmaxf(fmaf(acc.x + bi.x, al.x, be.x), 0.f);
-            y.y = fmaxf(fmaf(acc.y + bi.y, al.y, be.y), 0.f);
-            y.z = fmaxf(fmaf(acc.z + bi.z, al.z, be.z), 0.f);
-            y.w = fmaxf(fmaf(acc.w + bi.w, al.w, be.w), 0.f);
-            out4[((size_t)n * 16 + cq) * (size_t)(22 * 22) + p] = y;
         }
     }
 }
@@ -142,7 +147,7 @@ int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pi
                                 const float* alpha, const float* beta, float* out_c4, hipStream_t s) {
     if (!frames || !table || !total || !w9x64 || !bias || !alpha || !beta || !out_c4) return DCX_E_ARG;
     if (max_patches <= 0 || h <= 0 || w <= 0) return DCX_E_SHAPE;
-    dim3 grid(2, (unsigned)(max_patches < 65535 ? max_patches : 65535));
+    dim3 grid((unsigned)(max_patches < 65535 ? max_patches : 65535));
     hipLaunchKernelGGL(dcx_conv1_patches_kernel, grid, dim3(256), 0, s, frames, frame_stride, pitch, h, w, table, total,
                        max_patches, w9x64, bias, alpha, beta, out_c4);
     return (int)hipGetLastError();

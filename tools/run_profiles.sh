@@ -11,7 +11,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 if [ "$MODE" = collect ]; then
     mkdir -p "$OUT"; export TMPDIR=/tmp
-    (cd "$ROOT" && timeout 400 python bench.py --steps 20 --warmup 5 > "$OUT/bench.log" 2>&1; echo "bench exit $?" >> "$OUT/bench.log")
+    (cd "$ROOT" && timeout 400 python bench.py --steps 50 --warmup 5 > "$OUT/bench.log" 2>&1; echo "bench exit $?" >> "$OUT/bench.log")
     cd /tmp
     rm -rf "$OUT"/prof_r${R}*
     B="python $ROOT/bench.py --no-cpu-baseline --no-extras"

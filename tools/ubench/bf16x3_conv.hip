@@ -65,8 +65,9 @@ __global__ void split_kernel(const float* __restrict__ x, uint16_t* __restrict__
 
 // ws: bf16 [tap][C/16][3][cout][16];  out fp32 [n][H][W][cout] raw accumulators
 // workgroup = 4 waves = 64 couts x (4 rows x 64 pixels); wave = 64 couts x 64 pixels of one row: 2 x 2 tiles of 32x32
+template <int TERMS>
 __global__ __launch_bounds__(256) void conv_bf16x3_kernel(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ws,
-                                                          float* __restrict__ out, int n, int terms) {
+                                                          float* __restrict__ out, int n) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int tiles_x = W / 64;
@@ -79,21 +80,27 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(const uint16_t* __rest
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
         for (int ch = 0; ch < C / 16; ++ch) {
             bf16x8 a[2][3], bb[2][3];
+#pragma unroll
             for (int s = 0; s < 3; ++s) {
+#pragma unroll
                 for (int i = 0; i < 2; ++i)      // A: weights, row = cout
                     a[i][s] = *reinterpret_cast<const bf16x8*>(ws + ((((long)tap * (C / 16) + ch) * 3 + s) * C + i * 32 + l31) * 16 + half * 8);
+#pragma unroll
                 for (int j = 0; j < 2; ++j) {    // B: activations, column = pixel (padded coordinates: + dy, + dx)
                     const long px = ((long)b * HP + y + dy) * WP + x0 + j * 32 + l31 + dx;
                     bb[j][s] = *reinterpret_cast<const bf16x8*>(xs + (px * (C / 16) + ch) * 48 + s * 16 + half * 8);
                 }
             }
-            // six (terms = 6) or eight cross products, small ones first
-            static const int ia[8] = {1, 2, 1, 0, 2, 0, 1, 0}, ib[8] = {2, 1, 1, 2, 0, 1, 0, 0};
-            const int first = terms == 8 ? 0 : 2;
-            for (int q = first; q < 8; ++q)
+            // six (TERMS = 6) or eight cross products, small ones first (everything unrolled: operands must stay in registers)
+            constexpr int ia[8] = {1, 2, 1, 0, 2, 0, 1, 0}, ib[8] = {2, 1, 1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int q = 8 - TERMS; q < 8; ++q)
+#pragma unroll
                 for (int i = 0; i < 2; ++i)
+#pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ia[q]], bb[j][ib[q]], acc[i][j], 0, 0, 0);
         }
@@ -140,11 +147,15 @@ int main(int argc, char** argv) {
     std::vector<float> got(x.size());
     const double flop = 2.0 * npx * C * C * 9;
     for (int terms : {6, 8}) {
-        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n, terms);
+        auto launch = [&]() {
+            if (terms == 6) hipLaunchKernelGGL(conv_bf16x3_kernel<6>, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n);
+            else hipLaunchKernelGGL(conv_bf16x3_kernel<8>, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n);
+        };
+        for (int it = 0; it < 3; ++it) launch();
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0, 0));
         const int reps = 10;
-        for (int it = 0; it < reps; ++it) hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n, terms);
+        for (int it = 0; it < reps; ++it) launch();
         CHECK(hipEventRecord(e1, 0)); CHECK(hipDeviceSynchronize());
         float ms = 0.f; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
         CHECK(hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
