@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
     __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
     __shared__ float sp[24 * 24];                     // the normalised, zero-padded 24x24 patch (what extract_patches returns)
     const int n_end = min(max_patches, *total);
-    if ((int)blockIdx.x >= n_end) return;
+    if ((int)blockIdx.y >= n_end) return;
     const int tid = threadIdx.x;
+    const int cq0 = blockIdx.x * 4;                    // this workgroup's 16 output channels (4 workgroups per patch: the kernel is
+                                                       // latency-bound, not bandwidth-bound -- more, shorter workgroups)
     for (int i = tid; i < 9 * 64; i += 256) sw[i] = w9x64[i];
     if (tid < 64) {
         sw[576 + tid] = bias[tid];
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
     }
     const float4* sw4 = reinterpret_cast<const float4*>(sw);
     float4* out4 = reinterpret_cast<float4*>(out);
-    for (int n = blockIdx.x; n < n_end; n += gridDim.x) {     // one workgroup per patch (grid capped at 65535)
+    for (int n = blockIdx.y; n < n_end; n += gridDim.y) {     // gridDim.y is capped at 65535 patches
         const int4 t = reinterpret_cast<const int4*>(table)[n];
         const uint8_t* img = frames + (size_t)t.x * frame_stride;
         __syncthreads();                                       // previous patch's readers are done with sp
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) x[dy * 3 + dx] = sp[(oy + dy) * 24 + ox + dx];
-#pragma unroll 4
-            for (int cq = 0; cq < 16; ++cq) {
+#pragma unroll
+            for (int cq = cq0; cq < cq0 + 4; ++cq) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
@@ -147,7 +149,7 @@ int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pi
                                 const float* alpha, const float* beta, float* out_c4, hipStream_t s) {
     if (!frames || !table || !total || !w9x64 || !bias || !alpha || !beta || !out_c4) return DCX_E_ARG;
     if (max_patches <= 0 || h <= 0 || w <= 0) return DCX_E_SHAPE;
-    dim3 grid((unsigned)(max_patches < 65535 ? max_patches : 65535));
+    dim3 grid(4, (unsigned)(max_patches < 65535 ? max_patches : 65535));
     hipLaunchKernelGGL(dcx_conv1_patches_kernel, grid, dim3(256), 0, s, frames, frame_stride, pitch, h, w, table, total,
                        max_patches, w9x64, bias, alpha, beta, out_c4);
     return (int)hipGetLastError();
