@@ -139,11 +139,11 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
             // per item: 128 MFMAs of 32 cycles per unit + the transform's serial VALU + half an epilogue; stalls are hidden by the
             // co-resident workgroup (measured, tools/unit_probe.py); the 6x20 tile's transform reads are 2-way bank-conflicted
             double item_cost = (double)units * (64 * 64.0 + (c.tw == 20 ? 700.0 : 560.0)) + 2600.0;
-            if (c.acc_tiles == 4) {      // 16-tile items: only when every item is resident at once (2 per CU) -- then the launch takes
-                                         // one item's serial chain, which is half as long; never where the chip is full anyway
-                if (items > 2L * n_cu) continue;
-                item_cost = (double)units * (32 * 64.0 + 800.0) + 2200.0;
-            }
+            if (c.acc_tiles == 4)        // 16-tile items: half the serial chain per item, but twice the weight loads and 1.56x the halo per
+                                         // MFMA -- they win where a launch cannot fill the chip (bs = 1: the launch takes ONE item's chain)
+                                         // and where 32-tile items quantise badly (conv4a / conv4b at bs = 32: 768 items on 512 slots;
+                                         // measured 60.0 vs 63.5 us), nowhere else (conv3a 121 vs 107 us, heads 229 vs 196: tools/layer_table.py)
+                item_cost = (double)units * (32 * 64.0 + 600.0) + 2000.0;
             cost = (double)((items + n_cu - 1) / n_cu) * item_cost * (1.0 + 1e-6 * (double)items);   // ties: fewer work items
         } else if (c.fam == FAM_W2P) {   // 9 x 8 MFMAs of 32 cycles per unit; tiles are low-resolution, x4 phases
             const long wt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);

@@ -295,7 +295,9 @@ def test_tile_cost_model_choices():
     assert "DcxWino2hCfg<8,8,0,2>" in name(512, 128, 8, 8, 128, 3, 0, 0)                   # RefineNet conv3a/3b: two maps per item
     assert "DcxWino2hCfg<8,8,0,1,1>" in name(16, 128, 8, 8, 128, 3, 0, 0)                  # ... at bs=1 (16 patches): 16-tile items, half the serial chain (same bits)
     assert "DcxWino2hCfg<8,8,0,1,1>" in name(1, 128, 30, 40, 128, 3, 0, 0)                 # conv4a for ONE frame: 40 short items instead of 24 long ones
-    assert "DcxWino2hCfg<8,16,0,1>" in name(32, 128, 30, 40, 128, 3, 0, 0)                 # ... and never where the launch fills the chip
+    assert "DcxWino2hCfg<8,8,0,1,1>" in name(32, 128, 30, 40, 128, 3, 0, 0)                # ... and where 32-tile items quantise badly (768 items on 512 slots: measured 60 vs 63.5 us)
+    assert "DcxWino2hCfg<8,16,0,1>" in name(32, 64, 60, 80, 128, 3, 0, 0)                  # ... but not where the chip is well filled (conv3a: 107 vs 121 us)
+    assert "DcxWino2hCfg<8,16,0,1>" in name(128, 128, 60, 80, 128, 3, 0, 0)                # (conv4a of cfg3)
     assert name_ups(512, 64, 64, 64, 64, 3, 0, 2, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,16,DCX_EPI_HEAT,1>>"    # RefineNet head behind the x2 up-sampling
     assert name_ups(512, 128, 32, 32, 64, 3, 0, 0, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,16,DCX_EPI_BNRELU,1>>"  # conv5a
     assert name_ups(512, 128, 16, 16, 128, 3, 0, 0, 1) == "dcx_conv_wino2p_kernel<DcxWino2pCfg<8,8,DCX_EPI_BNRELU,2>>"   # conv4a: two 8x8 maps per item
