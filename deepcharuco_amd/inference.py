@@ -203,12 +203,10 @@ def unpack_results(packed: np.ndarray, batch: int, kmax: int, refined: bool) -> 
 def infer_batch(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX):
     """Batched infer_image: frames_gray (B,H,W) uint8 host array (or GPU tensor) -> list of B keypoint arrays.
 
-    Frames are independent (the reference has no cross-frame state): frame b's corners equal ``infer_image`` on that
-    frame alone wherever the arg-max decisions are not exact near-ties.  (The launcher may run a layer on a different
-    kernel family at B=32 than at B=1 -- direct vs Winograd -- so logits can differ in their last bits, <= ~1.5e-5;
-    a cell whose top-2 logits are closer than that may decode differently.  ``set_deterministic(True)`` pins one
-    summation order for every batch size at ~0.6x the throughput; see DESIGN.md "Numerics".)  If a frame fires more than
-    ``kmax`` cells the batch is re-run with a larger capacity (never silently truncated).
+    Frames are independent (the reference has no cross-frame state) and the kernel family of every layer depends on the
+    layer only, so frame b's corners are bit-identical to ``infer_image`` on that frame alone, whatever the
+    batch size.  If a frame fires more than ``kmax`` cells the batch is re-run with a larger capacity (never silently
+    truncated).
     """
     det, _ = _unwrap(deepc, refinenet)
     dev = det.device

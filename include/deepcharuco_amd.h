@@ -179,13 +179,13 @@ const char* dcx_conv_pick_name(int n, int cin, int ho, int wo, int cout, int ks,
 /* same for a layer whose input is read through a nearest x2 up-sampling (ho x wo = output size = 2 x the stored input) */
 const char* dcx_conv_pick_name_ups(int n, int cin, int ho, int wo, int cout, int ks, int pool, int epi, int ups);
 
-/* ---- deterministic mode -------------------------------------------------------------------
- * By default the launcher picks, per layer and launch size, between three kernel families (direct implicit GEMM, 1-D
- * and 2-D Winograd): results are bit-reproducible for a given (shape, batch, device), but a frame's logits may differ
- * in their last bits between batch sizes (the families round differently; arg-max outputs agree except on exact
- * near-ties, see DESIGN.md "Numerics").  dcx_set_deterministic(1) (or DCX_DETERMINISTIC=1 in the environment) forces
- * the direct kernels everywhere: one summation order per output element, independent of batch size, tile and CU
- * count, at about 0.6x the default throughput.  Process-global; set it before launching work.                        */
+/* ---- kernel families / deterministic mode -------------------------------------------------
+ * The kernel family of a layer (= the fp32 summation order of its outputs: direct implicit GEMM, 2-D Winograd F(2x2,3x3),
+ * or phases x Winograd F(2x2,2x2) behind an up-sampling) depends on the LAYER only, never on the batch size or launch size:
+ * a frame's results are bit-identical alone and inside any batch.  dcx_set_deterministic(1) (or
+ * DCX_DETERMINISTIC=1 in the environment) forces the direct family everywhere -- every multiply-add of the layers as written,
+ * the A/B reference of the Winograd families -- at about 0.5x the default throughput.  Process-global; callers that hold
+ * captured hipGraphs must re-capture after switching (the Python layer does).                                          */
 int dcx_set_deterministic(int enabled);
 int dcx_get_deterministic(void);
 
