@@ -790,7 +790,7 @@ def test_graph_cache_threads_modes_and_lifetime(dev):
     env = dict(os.environ)
     env.pop("DCX_FORCE_CFG", None)
     out = subprocess.run([sys.executable, "-c", _GRAPH_CACHE_SCRIPT.format(repo=REPO)], env=env, capture_output=True, text=True,
-                         timeout=240)
+                         timeout=600)
     steps = [l for l in out.stdout.splitlines() if l.startswith(("STEP", "RESULT"))]
     assert out.returncode == 0 and steps and steps[-1] == "RESULT ok", f"{steps}\n{out.stderr[-3000:]}"
 
@@ -1120,6 +1120,30 @@ def test_pitched_frame_buffer_through_c_abi(dev, golden_tiny):
         k = int(c0[i])
         assert torch.equal(r0[i, :k], r1[i, :k]) and torch.equal(x0[i, :k], x1[i, :k])
     assert np.array_equal(r0[0, :int(c0[0]), :2].numpy(), golden_tiny.fx["kpts"])
+
+
+@pytest.mark.parametrize("hw", [(88, 104), (136, 200), (8, 8), (24, 1024), (248, 328)])
+def test_odd_resolutions_multiples_of_8(dev, hw):
+    """Any H, W divisible by 8 is legal (the nets are fully convolutional): shapes whose maps are not
+    multiples of any tile (11x13, 17x25, 31x41 cells; a single cell; a 3-cell-high strip) through the batch path, 1 / 3 / 9
+    frames each (different launch sizes pick different tiles of the SAME family), every frame identical to the oracle and to
+    itself across batch sizes."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    h, w = hw
+    frames = np.concatenate([W.synthetic_frames("noise", 9100 + h, 5, h, w), W.synthetic_frames("board", 9200 + w, 4, h, w)])
+    cells = (h // 8) * (w // 8)
+    sd_dc = _calibrated(700 + h + w, frames, target_per_frame=max(1, min(10, cells // 3)))
+    sd_rn = W.synthetic_state_dict("refinenet", 701 + h)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    exp = [O.infer_image(None, 16, t_dc, t_rn, gray=f) for f in frames]
+    assert sum(e.shape[0] for e in exp if e.ndim == 2) >= 5
+    for B in (9, 3, 1):
+        got = infer_batch(frames[:B], 16, dc, rn, kmax=64)
+        for b in range(B):
+            assert got[b].shape == exp[b].shape and got[b].dtype == exp[b].dtype and np.array_equal(got[b], exp[b]), (hw, B, b)
 
 
 def test_large_patch_capacity(dev, golden_tiny):
