@@ -87,7 +87,7 @@ class GraphedPipeline:
 
 
 _CACHE_MAX = 8        # per detector: graphs pin ~25 MB of workspace per 320x240 shape
-_cache_lock = threading.Lock()
+_cache_lock = threading.RLock()         # re-entrant: dropping a pipeline may run model destructors that come back here
 _graph_lock = threading.RLock()          # serialises hipGraph capture AND replay (+ the synchronise that follows) process-wide
 _caches: "weakref.WeakSet" = weakref.WeakSet()     # the per-detector caches that exist (for clear_graph_cache())
 
@@ -105,24 +105,29 @@ def graphs_usable() -> bool:
 
 def clear_graph_cache(deepc=None) -> None:
     """Drop the captured graphs (and their pinned / workspace buffers) of one detector, or of all of them."""
-    with _cache_lock:
+    victims = []                        # destroyed AFTER the lock is released: a pipeline may hold the last reference to a model,
+    with _cache_lock:                   # whose destructor calls back into this module
         if deepc is not None:
             det = deepc.model if hasattr(deepc, "model") else deepc
-            c = getattr(det, "_graph_cache", None)
-            if c is not None:
+            caches = [getattr(det, "_graph_cache", None)]
+        else:
+            caches = list(_caches)
+        for c in caches:
+            if c:
+                victims.extend(c.values())
                 c.clear()
-            return
-        for c in list(_caches):
-            c.clear()
+    del victims
 
 
 def drop_graphs_of_refiner(ref) -> None:
     """Called when a RefineNet releases its C handle (reload / ``to(device)`` / destruction): graphs captured with it hold
     pointers into the freed weights."""
+    victims = []
     with _cache_lock:
         for c in list(_caches):
             for k in [k for k in c if k[0] is not None and k[0][0] == id(ref)]:
-                c.pop(k, None)
+                victims.append(c.pop(k, None))
+    del victims
 
 
 def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int, bgr: bool,

@@ -65,8 +65,10 @@ class dcModel:
     def _release(self):
         if self._handle is not None:
             cache = getattr(self, "_graph_cache", None)      # hipGraphs captured with this handle's weights (graph.py)
-            if cache is not None:
+            if cache:
+                victims = list(cache.values())
                 cache.clear()
+                del victims
             _lib.lib().dcx_detector_destroy(self._handle)
             self._handle = None
 

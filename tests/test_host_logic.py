@@ -375,6 +375,38 @@ def test_conv_kernels_do_not_spill():
             assert "scratch_" not in b and b.count("v_accvgpr") <= 8, f"{m.group(1)}: spill inside the unit loop"
 
 
+def test_graph_cache_clear_is_reentrant():
+    """A cached GraphedPipeline may hold the LAST reference to a model pair; dropping it (clear_graph_cache, e.g. from
+    set_deterministic) then runs RefineNet._release -> drop_graphs_of_refiner, which comes back to the cache lock on the same
+    thread.  Found as a hang of the GPU suite in round 3; reproduced here without a GPU, under a watchdog."""
+    import threading
+    from deepcharuco_amd import graph as G
+
+    class Pipe:
+        def __init__(self, ref):
+            self.ref = ref
+
+        def __del__(self):
+            G.drop_graphs_of_refiner(self.ref)
+
+    class Det:
+        pass
+    det, cache = Det(), G._Cache()
+    det._graph_cache = cache
+    G._caches.add(cache)
+    cache[((1, 2), 16, 8, 8, True, 64, 0)] = Pipe(object())
+    done = []
+    t = threading.Thread(target=lambda: (G.clear_graph_cache(), done.append(1)), daemon=True)
+    t.start()
+    t.join(20)
+    assert done and len(cache) == 0, "clear_graph_cache dead-locked on its own lock"
+    cache[((3, 4), 16, 8, 8, True, 64, 0)] = Pipe(object())
+    t = threading.Thread(target=lambda: (G.clear_graph_cache(det), done.append(2)), daemon=True)
+    t.start()
+    t.join(20)
+    assert done == [1, 2] and len(cache) == 0
+
+
 def test_missing_native_library_fails_loudly(monkeypatch, tmp_path):
     """No fallback: without libdeepcharuco_amd.so every entry into the library raises (nothing is computed on the
     CPU or through stock PyTorch operators instead)."""
