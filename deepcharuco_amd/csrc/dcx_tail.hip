@@ -22,7 +22,7 @@ typedef float dcx_t_f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int kTailPF = 4;   // prefetch distance in k-steps (each 4 x NT x 64 MFMA cycles)
+constexpr int kTailPF = 2;   // prefetch distance in k-steps (measured at bs=32 with 32-cell items: 1 -> 30.8 us, 2 -> 29.4, 3 -> 30.7, 4 -> 31.9, 8 -> 37.1)
 
 template <int NT, int IDS_TILES>
 __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict__ act, int act_cq_total, int cells,
@@ -153,10 +153,9 @@ int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, 
     if (batch <= 0 || cells <= 0 || n_ids1 < 2 || n_ids1 > 64 || ids_cout_pad < n_ids1) return DCX_E_SHAPE;
     if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
     const bool two = n_ids1 > 32;
-    // 64-cell items amortise the weight fetch when there is plenty of work; 32-cell items spread a small launch over more CUs
-    const long items64 = (long)batch * ((cells + 63) / 64);
-    const bool nt2 = items64 >= 512;
-    const int npix = nt2 ? 64 : 32;
+    // 32-cell work items: the kernel is latency-bound (operands straight from L2 / HBM into registers), so more, shorter
+    // workgroups per CU win at every size (64-cell items: 41 vs 32 us at bs=32, 139 vs 119 at bs=128, 469 vs 446 at bs=128 640x480)
+    const int npix = 32;
     const int tiles = (cells + npix - 1) / npix;
     const long items = (long)batch * tiles;
     if (items > 0x7fffffffL) return DCX_E_SHAPE;
@@ -166,8 +165,7 @@ int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, 
 #define DCX_TAIL_LAUNCH(NT, IT)                                                                                          \
     hipLaunchKernelGGL((dcx_tail_kernel<NT, IT>), dim3((unsigned)items), dim3(256), 0, s, a4, 128, cells, wl, b_loc, wi, b_ids, \
                        ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax, zero_word)
-    if (nt2) { if (two) DCX_TAIL_LAUNCH(2, 2); else DCX_TAIL_LAUNCH(2, 1); }
-    else     { if (two) DCX_TAIL_LAUNCH(1, 2); else DCX_TAIL_LAUNCH(1, 1); }
+    if (two) DCX_TAIL_LAUNCH(1, 2); else DCX_TAIL_LAUNCH(1, 1);
 #undef DCX_TAIL_LAUNCH
     return (int)hipGetLastError();
 }
