@@ -512,7 +512,7 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* f
     const int* lim = d_total;
     // conv1a (pad 0) 24 -> 22 (refinenet.py:56); in the pipeline fused with extract_patches (model_utils.py:19-36)
     int rc = fsrc != nullptr
-        ? dcx_launch_conv1_patches_u8(fsrc->frames, fsrc->frame_stride, fsrc->pitch, fsrc->height, fsrc->width, d_table, d_total, p,
+        ? dcx_launch_conv1_patches_u8(fsrc->frames, fsrc->frame_stride, fsrc->pitch, fsrc->height, fsrc->width, d_table, d_total, p, n_hint,
                                       rf->first.w, rf->first.bias, rf->first.alpha, rf->first.beta, buf0, s)
         : dcx_launch_conv1_f32(d_patches, 576, 24, p, 24, 24, 0, rf->first.w, rf->first.bias, rf->first.alpha,
                                rf->first.beta, buf0, lim, s);

@@ -100,7 +100,7 @@ int dcx_launch_compact_table(const int32_t* codes, int batch, int hc, int wc, in
 // RefineNet conv1a (pad 0, 24x24 -> 22x22) reading its patches straight out of the u8 frames through the patch table
 // (extract_patches + pre_bgr_image + conv1a in one kernel: the patch tensor is never materialised)
 int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int h, int w, const int32_t* table,
-                                const int* total, int max_patches, const float* w9x64, const float* bias,
+                                const int* total, int max_patches, int n_hint, const float* w9x64, const float* bias,
                                 const float* alpha, const float* beta, float* out_c4, hipStream_t s);
 int dcx_launch_refine_finalize(const float* part_val, const int* part_idx, int tiles, int wo,
                                int max_patches, const int* total, const int32_t* table,

@@ -88,6 +88,9 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
                                                                   float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
     __shared__ float sp[24 * 24];                     // the normalised, zero-padded 24x24 patch (what extract_patches returns)
+    // the first patch's table entry is requested together with the live-patch count (the slot exists for every blockIdx.y; its
+    // content is only used if the patch is live): one L2 / HBM latency instead of two at the head of a latency-bound kernel
+    int4 t = reinterpret_cast<const int4*>(table)[blockIdx.y];
     const int n_end = min(max_patches, *total);
     if ((int)blockIdx.y >= n_end) return;
     const int tid = threadIdx.x;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
     const float4* sw4 = reinterpret_cast<const float4*>(sw);
     float4* out4 = reinterpret_cast<float4*>(out);
     for (int n = blockIdx.y; n < n_end; n += gridDim.y) {     // gridDim.y is capped at 65535 patches
-        const int4 t = reinterpret_cast<const int4*>(table)[n];
+        if (n != (int)blockIdx.y) t = reinterpret_cast<const int4*>(table)[n];
         const uint8_t* img = frames + (size_t)t.x * frame_stride;
         __syncthreads();                                       // previous patch's readers are done with sp
         for (int e = tid; e < 576; e += 256) {
@@ -145,11 +148,15 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
 }
 
 int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int h, int w, const int32_t* table,
-                                const int* total, int max_patches, const float* w9x64, const float* bias,
+                                const int* total, int max_patches, int n_hint, const float* w9x64, const float* bias,
                                 const float* alpha, const float* beta, float* out_c4, hipStream_t s) {
     if (!frames || !table || !total || !w9x64 || !bias || !alpha || !beta || !out_c4) return DCX_E_ARG;
     if (max_patches <= 0 || h <= 0 || w <= 0) return DCX_E_SHAPE;
-    dim3 grid(4, (unsigned)(max_patches < 65535 ? max_patches : 65535));
+    // The grid covers the EXPECTED number of live patches (n_hint; the kernel strides over the rest): workgroups that only find
+    // out that their slot is dead still cost a dispatch each, and at ~3 ns per workgroup 8,192 of them were the whole 24 us
+    int gy = n_hint > 0 && n_hint < max_patches ? n_hint : max_patches;
+    if (gy > 65535) gy = 65535;
+    dim3 grid(4, (unsigned)gy);
     hipLaunchKernelGGL(dcx_conv1_patches_kernel, grid, dim3(256), 0, s, frames, frame_stride, pitch, h, w, table, total,
                        max_patches, w9x64, bias, alpha, beta, out_c4);
     return (int)hipGetLastError();
