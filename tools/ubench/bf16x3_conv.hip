@@ -114,6 +114,65 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(const uint16_t* __rest
             }
 }
 
+
+// The same computation with the activation halo tile of a 16-channel chunk staged in LDS (6 rows x 66 pixels x 3 splits x 16
+// channels; pixel stride 112 B so that the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots), weights from L2.
+// Still a prototype (single-buffered, two barriers per chunk, no software pipelining) -- three workgroups per CU cover the stalls.
+constexpr int PXB = 112;                       // bytes per pixel in LDS: 96 payload + 16 pad
+__global__ __launch_bounds__(256, 3) void conv_bf16x3_lds_kernel(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ws,
+                                                                 float* __restrict__ out, int n) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[6 * 66 * PXB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tiles_x = W / 64;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % (H / 4);
+    const int b = t / (H / 4);
+    const int y0 = ty * 4, x0 = tx * 64;       // padded coordinates of the halo tile's top-left pixel
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int ch = 0; ch < C / 16; ++ch) {
+        __syncthreads();
+        for (int idx = tid; idx < 6 * 66 * 6; idx += 256) {
+            const int px = idx / 6, part = idx - px * 6;
+            const int r = px / 66, c = px - r * 66;
+            const uint4 v = *reinterpret_cast<const uint4*>(xs + ((((long)b * HP + y0 + r) * WP + x0 + c) * (C / 16) + ch) * 48 + part * 8);
+            *reinterpret_cast<uint4*>(sX + px * PXB + part * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            bf16x8 a[2][3], bb[2][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i][s] = *reinterpret_cast<const bf16x8*>(ws + ((((long)tap * (C / 16) + ch) * 3 + s) * C + i * 32 + l31) * 16 + half * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bb[j][s] = *reinterpret_cast<const bf16x8*>(sX + ((wave + dy) * 66 + j * 32 + l31 + dx) * PXB + s * 32 + half * 16);
+            }
+            constexpr int ia[6] = {1, 0, 2, 0, 1, 0}, ib[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ia[q]], bb[j][ib[q]], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int y = y0 + wave;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) {
+                const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[(((long)b * H + y) * W + x0 + j * 32 + l31) * C + co] = acc[i][j][r];
+            }
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 8;
     const long npx = (long)n * H * W;
@@ -146,10 +205,11 @@ int main(int argc, char** argv) {
     const unsigned grid = (unsigned)(n * (H / 4) * (W / 64));
     std::vector<float> got(x.size());
     const double flop = 2.0 * npx * C * C * 9;
-    for (int terms : {6, 8}) {
+    for (int terms : {6, 8, 60}) {           // 60: six terms, LDS-staged kernel
         auto launch = [&]() {
             if (terms == 6) hipLaunchKernelGGL(conv_bf16x3_kernel<6>, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n);
-            else hipLaunchKernelGGL(conv_bf16x3_kernel<8>, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n);
+            else if (terms == 8) hipLaunchKernelGGL(conv_bf16x3_kernel<8>, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n);
+            else hipLaunchKernelGGL(conv_bf16x3_lds_kernel, dim3(grid), dim3(256), 0, 0, d_xs, d_ws, d_out, n);
         };
         for (int it = 0; it < 3; ++it) launch();
         CHECK(hipDeviceSynchronize());
@@ -183,9 +243,9 @@ int main(int argc, char** argv) {
                 sum_bf += ebf; sum_f32 += ef; ++cnt;
             }
         }
-        printf("bf16x3 %d terms: %8.3f ms for %d frames  %7.1f TFLOP/s (fp32-equivalent, algorithmic)  | error vs fp64 over %ld outputs: "
+        printf("bf16x3 %d terms%s: %8.3f ms for %d frames  %7.1f TFLOP/s (fp32-equivalent, algorithmic)  | error vs fp64 over %ld outputs: "
                "bf16x3 max %.3e mean %.3e   fp32 fmaf chain (direct kernel's order) max %.3e mean %.3e\n",
-               terms, ms, n, flop / (ms * 1e-3) / 1e12, cnt, max_bf, sum_bf / cnt, max_f32, sum_f32 / cnt);
+               terms == 60 ? 6 : terms, terms == 60 ? " (LDS-staged)" : "", ms, n, flop / (ms * 1e-3) / 1e12, cnt, max_bf, sum_bf / cnt, max_f32, sum_f32 / cnt);
     }
     return 0;
 }
