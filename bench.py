@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- end-to-end frames/s of the detect+refine path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5]       (N=1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5]
+      N = 1: runs in this process.  N > 1 from a bare shell (no RANK/WORLD_SIZE): starts its own N ranks under
+      torch.distributed.run on 127.0.0.1 at a free port (self_launch) and relays rank 0's JSON line + the exit code.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (ranks started by the caller)
 
 A "step" = one pass of the whole hot path (detector -> decode -> patch gather -> RefineNet -> sub-pixel xy, + for N>1
 one RCCL all-gather of the packed corner lists, issued on a side stream so that it overlaps the next step's
@@ -460,6 +462,30 @@ def exploratory_bf16x3():
     return res
 
 
+def self_launch(n, backend, argv):
+    """`python bench.py --gpus N` from a bare shell (no RANK/WORLD_SIZE in the environment) for N > 1: start the N ranks
+    ourselves under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port), forward every flag,
+    let the ranks' stdout through (rank 0 prints the single JSON line) and return the launcher's exit code.  RCCL needs one
+    GPU per rank: with fewer GPUs visible this is an error, never a silent gloo run."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} with backend nccl (RCCL) but only {ndev} GPU(s) visible; "
+              "pass --backend gloo explicitly to smoke-test the multi-process flow on fewer GPUs", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -484,16 +510,20 @@ def main():
                          "with several ranks on one GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, args.backend, sys.argv[1:]))
+
     cx = Ctx()
     cx.rank = rank = int(os.environ.get("RANK", "0"))
     cx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cx.backend = args.backend
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     ndev = torch.cuda.device_count()
     if args.backend == "nccl" and world > ndev:
-        raise SystemExit(f"{world} ranks but only {ndev} GPUs visible")
+        raise SystemExit(f"{world} ranks but only {ndev} GPUs visible: RCCL needs one GPU per rank (no silent gloo fallback; "
+                         "--backend gloo is an explicit smoke-test mode)")
     torch.cuda.set_device(local_rank % ndev)
     cx.dev = dev = torch.device("cuda", local_rank % ndev)
     cx.dist = None
@@ -508,6 +538,12 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         cx.dist = dist
+        # what the process group really is: rank count seen by RCCL / gloo and the device every rank computes on
+        objs = [None] * world
+        dist.all_gather_object(objs, {"rank": rank, "device": int(dev.index), "pid": os.getpid()})
+        cx.ranks_seen = {"world_size": int(dist.get_world_size()), "backend": dist.get_backend(),
+                         "device_of_rank": [o["device"] for o in objs], "visible_gpus": ndev,
+                         "distinct_processes": len({o["pid"] for o in objs})}
     cx.L = _lib.lib()
 
     p = dict(WL.PRESETS[args.config])
@@ -557,6 +593,8 @@ def main():
                        "'>200 fps' (GTX1080Ti, bs=1, src/benchmark.py) is compared like for like in other_configs.bs1_reference_protocol"),
         "parity": main_res["parity"],
     }
+    if dist_on:
+        line["ranks"] = cx.ranks_seen
     for k_ in ("gather_overlapped", "roofline", "cpu_baseline"):
         if k_ in main_res:
             line[k_] = main_res[k_]

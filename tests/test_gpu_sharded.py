@@ -108,3 +108,45 @@ def test_bench_n_gt_1_code_path_with_one_rccl_rank(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["gather_overlapped"] is True and line["parity"]["mismatched_frames"] == 0 and line["parity"]["frames_checked"] >= 4
     assert line["n_gpus"] == 1 and line["value"] > 1000
+
+
+_LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                  "TORCHELASTIC_RUN_ID", "DCX_FORCE_CFG")
+
+
+def _bare_env():
+    return {k: v for k, v in os.environ.items() if k not in _LAUNCHER_VARS}
+
+
+def test_bench_self_launches_its_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2 ...` exactly as the driver starts it (no RANK / WORLD_SIZE / MASTER_* in the environment):
+    bench.py starts its own two ranks under torch.distributed.run, rank 0 prints ONE JSON line with n_gpus = 2, frames of BOTH
+    ranks' timed batches are identical to the oracle, exit code 0.  gloo because the box has one GPU (RCCL when it has two)."""
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", backend, "--steps", "2",
+                        "--warmup", "1", "--no-extras"], env=_bare_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["ranks"]["world_size"] == 2 and line["ranks"]["distinct_processes"] == 2 and line["ranks"]["backend"] == backend
+    assert line["parity"]["mismatched_frames"] == 0 and line["parity"]["frames_checked"] >= 10     # 8 of rank 0 + >= 2 of rank 1
+    assert line["gather_overlapped"] in (True, False) and line["value"] > 1000
+
+
+def test_bench_refuses_rccl_with_fewer_gpus_than_ranks():
+    """Never a silent gloo: --gpus N with the default backend (RCCL) and fewer than N visible GPUs is a clear error."""
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                        "--no-extras"], env=_bare_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_single_gpu_line_has_no_rank_block():
+    """--gpus 1 stays a single in-process run: no process group, no `ranks` block, n_gpus = 1."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], env=_bare_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and "ranks" not in line and "gather_overlapped" not in line and "roofline" in line
