@@ -180,7 +180,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     # ---- weights: every rank calibrates on the SAME frames (rank 0's first batch), so all ranks run identical weights
     calib_kind = frames_kind
     calib = torch.from_numpy(W.synthetic_frames(calib_kind, FRAME_SEED, min(B, 128), H, Wd)).to(dev)
-    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), calib, dev)
+    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), calib, dev, diverse_ids=True)
     del calib
     sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
@@ -306,6 +306,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                     "algorithmic_gflop_per_launch": round(flop / launches / 1e9, 3),
                     "traffic": pmc_traffic(kname(dom_id)),
                     "shader_clock_ghz": round(clk / msum, 3),
+                    # executed matrix FLOP of one whole step / the step's wall time (timed region) / peak
+                    "e2e_executed_frac": round(conv_exec / extra_steps / (elapsed / steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                     "all_conv_kernels": {"achieved": round(conv_exec / (conv_ms * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(conv_ms / extra_steps, 3),
                                          "frac": round(conv_exec / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -322,6 +324,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         return None
 
     counts = np.concatenate([unpack_results(p, B, kmax, True)[1] for p in per_rank])
+    ids_seen = sorted({int(i) for r in res_local if r.ndim == 2 for i in r[:, 2]})
     mean_k = float(np.minimum(counts, kmax).mean())
     overflow = int((counts > kmax).sum())
     fps = world * B * steps / elapsed
@@ -354,11 +357,14 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                    "batch_per_gpu": B, "global_batch": B * world, "height": H, "width": Wd, "kmax": kmax,
                    "frames": frames_kind, "mean_corners_per_frame": round(mean_k, 2), "frames_over_kmax": overflow,
                    "corners_per_frame_min_max": [int(counts.min()), int(counts.max())],
-                   "weights": "numpy-seeded synthetic (seed 1234/1235), dust-bin bias calibrated to ~16 corners/frame"
+                   "distinct_ids_in_batch": len(ids_seen),
+                   "weights": "numpy-seeded synthetic (seed 1234/1235), ids-head biases equalised per class (all ids fire), dust-bin bias calibrated to ~16 corners/frame"
                               + (f"; frames selected by the workload generator so that exactly {fixed_k} cells fire in each" if fixed_k else ""),
                    "parallelism": f"frames sharded, 1 process/GPU x{world}" + (", RCCL all-gather of corner lists on a side stream" if world > 1 else ""),
                    "algorithmic_gflop_per_frame": round(gflop_frame, 3),
-                   "e2e_frac_of_f32_mfma_peak": round(fps * gflop_frame / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
+                   # the layers AS WRITTEN / peak: > 1 is possible because the Winograd families execute 4/9 (1/4) of those MACs;
+                   # the executed fraction of the whole step is roofline.e2e_executed_frac
+                   "e2e_algorithmic_over_peak": round(fps * gflop_frame / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
         "parity": parity,
     }
     if dist_on:
@@ -380,7 +386,7 @@ def two_stream_pipelined(cx, steps=40, warmup=6):
     p = WL.PRESETS["cfg2"]
     B, H, Wd, kmax = p["batch"], p["height"], p["width"], p["kmax"]
     frames = [W.synthetic_frames("board", FRAME_SEED + 500 * i, B, H, Wd) for i in range(2)]
-    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames[0]).to(dev), dev)
+    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames[0]).to(dev), dev, diverse_ids=True)
     sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
     d = [torch.from_numpy(f).to(dev) for f in frames]
@@ -417,7 +423,7 @@ def bs1_reference_protocol(cx, n_iter=500):
     infer_image calls (BGR->gray, H2D, both nets, D2H, sort inside every call), fps = n / elapsed."""
     dev = cx.dev
     frames = W.synthetic_frames("board", FRAME_SEED, 32, 240, 320)
-    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames).to(dev), dev)
+    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames).to(dev), dev, diverse_ids=True)
     sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
     bgr = np.ascontiguousarray(np.repeat(frames[0][..., None], 3, axis=2))

@@ -54,6 +54,7 @@ SIGNATURES = {
     "dcx_detector_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "dcx_refiner_workspace_bytes": (_sz, [_vp, _i]),
     "dcx_bgr2gray": (_i, [_vp, _l, _i, _i, _i, _i, _vp, _vp]),
+    "dcx_bgr2gray_legacy14": (_i, [_vp, _l, _i, _i, _i, _i, _vp, _vp]),
     "dcx_pre_image": (_i, [_vp, _vp, _sz, _vp]),
     "dcx_detector_forward": (_i, [_vp, _vp, _l, _i, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "dcx_detector_decode": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -624,12 +624,20 @@ extern "C" int dcx_pre_image(const uint8_t* d_gray, float* d_out, size_t n, void
     return (int)hipGetLastError();
 }
 
-// cv2.cvtColor(img, COLOR_BGR2GRAY) on 8-bit images (call site /root/reference/src/inference.py:40): OpenCV's fixed-point
-// formula with 14 fractional bits, gray = (1868 B + 9617 G + 4899 R + 8192) >> 14 -- integer arithmetic, so the device
-// result equals the host restatement (deepcharuco_amd/imgproc.py, oracle bgr2gray) bit for bit.  One thread = 4 pixels
-// (12 B in, 4 B out); the numpy version of this costs the host 150-300 us per 320x240 frame, more than half of a bs=1 call.
+// cv2.cvtColor(img, COLOR_BGR2GRAY) on 8-bit images (call site /root/reference/src/inference.py:40).  OpenCV is third-party and
+// not vendored; the reference pins opencv-contrib-python >= 4.6, < 4.12 (requirements.txt:5; src/requirements.txt: 4.6.0.66).
+// OpenCV 4.x, modules/imgproc/src/color.hpp + color_rgb.simd.hpp, RGB2Gray<uchar>: gray_shift = 15, RY15 / GY15 / BY15 =
+// 9798 / 19235 / 3735 (= 0.299 / 0.587 / 0.114 x 32768, rounded; they sum to 32768):
+//     gray = (3735 B + 19235 G + 9798 R + 16384) >> 15                                   <- dcx_bgr2gray (CB, CG, CR, SHIFT below)
+// The 14-bit constants R2Y / G2Y / B2Y = 4899 / 9617 / 1868 (yuv_shift = 14), which older OpenCV generations also used for 8-bit
+// gray, survive in 4.x only for 16-bit images and YUV:  gray = (1868 B + 9617 G + 4899 R + 8192) >> 14  <- dcx_bgr2gray_legacy14.
+// The two differ by one gray level on ~0.26 % of colour pixels (never on B = G = R).  Integer arithmetic, so the device result
+// equals the host restatement (deepcharuco_amd/imgproc.py, oracle bgr2gray) bit for bit.  One thread = 4 pixels (12 B in, 4 B
+// out); the numpy version of this costs the host 150-300 us per 320x240 frame, more than half of a bs=1 call.
+template <unsigned CB, unsigned CG, unsigned CR, int SHIFT>
 __global__ __launch_bounds__(256) void dcx_bgr2gray_kernel(const uint8_t* __restrict__ bgr, long frame_stride, int pitch,
                                                              int h, int w, uint8_t* __restrict__ gray) {
+    static_assert(CB + CG + CR == (1u << SHIFT), "the weights of a gray conversion sum to one");
     const int b = blockIdx.z, y = blockIdx.y;
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (x0 >= w) return;
@@ -639,20 +647,31 @@ __global__ __launch_bounds__(256) void dcx_bgr2gray_kernel(const uint8_t* __rest
     uint8_t g[4] = {0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         const unsigned bb = src[3 * i], gg = src[3 * i + 1], rr = src[3 * i + 2];
-        g[i] = (uint8_t)((bb * 1868u + gg * 9617u + rr * 4899u + 8192u) >> 14);
+        g[i] = (uint8_t)((bb * CB + gg * CG + rr * CR + (1u << (SHIFT - 1))) >> SHIFT);
     }
     if (n == 4 && ((w & 3) == 0)) *reinterpret_cast<uchar4*>(dst) = make_uchar4(g[0], g[1], g[2], g[3]);
     else for (int i = 0; i < n; ++i) dst[i] = g[i];
 }
 
-extern "C" int dcx_bgr2gray(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
-                            uint8_t* d_gray, void* stream) {
+template <unsigned CB, unsigned CG, unsigned CR, int SHIFT>
+static int bgr2gray_launch(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
+                           uint8_t* d_gray, void* stream) {
     if (!d_bgr || !d_gray) return DCX_E_ARG;
     if (batch <= 0 || height <= 0 || width <= 0 || batch > 65535 || height > 65535 || pitch < 3 * width) return DCX_E_SHAPE;
     const dim3 grid((unsigned)((width + 1023) / 1024), (unsigned)height, (unsigned)batch);
-    hipLaunchKernelGGL(dcx_bgr2gray_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_bgr, frame_stride, pitch, height, width,
-                       d_gray);
+    hipLaunchKernelGGL((dcx_bgr2gray_kernel<CB, CG, CR, SHIFT>), grid, dim3(256), 0, (hipStream_t)stream, d_bgr, frame_stride,
+                       pitch, height, width, d_gray);
     return (int)hipGetLastError();
+}
+
+extern "C" int dcx_bgr2gray(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
+                            uint8_t* d_gray, void* stream) {
+    return bgr2gray_launch<3735u, 19235u, 9798u, 15>(d_bgr, frame_stride, pitch, batch, height, width, d_gray, stream);
+}
+
+extern "C" int dcx_bgr2gray_legacy14(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
+                                     uint8_t* d_gray, void* stream) {
+    return bgr2gray_launch<1868u, 9617u, 4899u, 14>(d_bgr, frame_stride, pitch, batch, height, width, d_gray, stream);
 }
 
 // NCHW [n][c][hw] <-> C4 [n][ceil(c/4)][hw][4]

@@ -17,38 +17,68 @@ def _opencv():
     return _cv2
 
 
+# cv2.cvtColor(img, COLOR_BGR2GRAY) on 8-bit images: (cB, cG, cR, shift) of gray = (cB*B + cG*G + cR*R + (1 << (shift-1))) >> shift.
+#   "opencv4"  -- OpenCV 4.x (the range the reference pins: opencv-contrib-python >= 4.6, < 4.12, requirements.txt:5):
+#                 imgproc/src/color.hpp `gray_shift = 15, RY15 = 9798, GY15 = 19235, BY15 = 3735`, used by RGB2Gray<uchar>
+#                 (imgproc/src/color_rgb.simd.hpp; its SIMD and scalar branches compute the same integer expression).
+#   "legacy14" -- the 14-bit constants `R2Y = 4899, G2Y = 9617, B2Y = 1868` (yuv_shift = 14) that older OpenCV generations also
+#                 used for 8-bit gray; in 4.x they remain for 16-bit images and the YUV conversions only.
+# The two differ by one gray level on ~0.26 % of colour pixels and never when B = G = R.
+BGR2GRAY_VARIANTS = {"opencv4": (3735, 19235, 9798, 15), "legacy14": (1868, 9617, 4899, 14)}
+DEFAULT_BGR2GRAY = "opencv4"
+
+
+def bgr2gray_variant_of_opencv(version: str) -> str:
+    """Which fixed-point variant a given ``cv2.__version__`` computes for 8-bit BGR->gray (4.x: 15-bit; before: 14-bit)."""
+    try:
+        major = int(str(version).split(".")[0])
+    except ValueError:
+        return DEFAULT_BGR2GRAY
+    return "opencv4" if major >= 4 else "legacy14"
+
+
+def bgr2gray_fixed_point(img_bgr: np.ndarray, variant: str = DEFAULT_BGR2GRAY) -> np.ndarray:
+    """The integer formula itself (never cv2): what the device kernels ``dcx_bgr2gray`` / ``dcx_bgr2gray_legacy14`` compute."""
+    if img_bgr.ndim < 3 or img_bgr.shape[-1] != 3 or img_bgr.dtype != np.uint8:
+        raise ValueError("expected a (...,H,W,3) uint8 BGR image")
+    cb, cg, cr, shift = BGR2GRAY_VARIANTS[variant]
+    acc = img_bgr[..., 0].astype(np.uint32) * np.uint32(cb)
+    acc += img_bgr[..., 1].astype(np.uint32) * np.uint32(cg)
+    acc += img_bgr[..., 2].astype(np.uint32) * np.uint32(cr)
+    acc += np.uint32(1 << (shift - 1))
+    acc >>= np.uint32(shift)
+    return acc.astype(np.uint8)
+
+
 def bgr2gray(img_bgr: np.ndarray) -> np.ndarray:
     """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) (call site /root/reference/src/inference.py:40).
 
-    Uses OpenCV when it is importable; otherwise OpenCV's published 8-bit fixed-point formula
-    gray = (1868*B + 9617*G + 4899*R + 8192) >> 14.
+    Uses OpenCV when it is importable (what the reference calls); otherwise the 8-bit fixed-point formula of the OpenCV
+    generation the reference pins (4.x): gray = (3735*B + 19235*G + 9798*R + 16384) >> 15.
     """
     cv2 = _opencv()
     if cv2:
         return cv2.cvtColor(img_bgr, cv2.COLOR_BGR2GRAY)
-    if img_bgr.ndim != 3 or img_bgr.shape[2] != 3 or img_bgr.dtype != np.uint8:
+    if img_bgr.ndim != 3:
         raise ValueError("expected a (H,W,3) uint8 BGR image")
-    acc = img_bgr[..., 0].astype(np.uint32) * np.uint32(1868)
-    acc += img_bgr[..., 1].astype(np.uint32) * np.uint32(9617)
-    acc += img_bgr[..., 2].astype(np.uint32) * np.uint32(4899)
-    acc += np.uint32(8192)
-    acc >>= np.uint32(14)
-    return acc.astype(np.uint8)
+    return bgr2gray_fixed_point(img_bgr, DEFAULT_BGR2GRAY)
 
 
-def bgr2gray_device(bgr):
-    """Device version (``dcx_bgr2gray``): (B,H,W,3) or (H,W,3) uint8 GPU tensor -> (B,H,W) / (H,W) uint8 gray on the GPU,
-    same fixed-point formula as :func:`bgr2gray`'s fallback (bit-identical; the numpy version costs the host more than half
-    of a bs=1 ``infer_image`` call)."""
+def bgr2gray_device(bgr, variant: str = DEFAULT_BGR2GRAY):
+    """Device version (``dcx_bgr2gray``; ``variant="legacy14"``: ``dcx_bgr2gray_legacy14``): (B,H,W,3) or (H,W,3) uint8 GPU
+    tensor -> (B,H,W) / (H,W) uint8 gray on the GPU, the same integer formula as :func:`bgr2gray_fixed_point` (bit-identical;
+    the numpy version costs the host more than half of a bs=1 ``infer_image`` call)."""
     import torch
     from . import _lib
     if bgr.device.type != "cuda" or bgr.dtype != torch.uint8 or bgr.shape[-1] != 3 or bgr.ndim not in (3, 4):
         raise ValueError("expected a (B,H,W,3) or (H,W,3) uint8 tensor on the GPU")
+    if variant not in BGR2GRAY_VARIANTS:
+        raise ValueError(f"unknown BGR->gray variant {variant!r}")
     x = bgr.contiguous()
     b = 1 if x.ndim == 3 else x.shape[0]
     h, w = x.shape[-3], x.shape[-2]
     gray = torch.empty(x.shape[:-1], dtype=torch.uint8, device=x.device)
+    fn = _lib.lib().dcx_bgr2gray if variant == "opencv4" else _lib.lib().dcx_bgr2gray_legacy14
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().dcx_bgr2gray(x.data_ptr(), h * w * 3, w * 3, b, h, w, gray.data_ptr(), _lib.current_stream()),
-                   "dcx_bgr2gray")
+        _lib.check(fn(x.data_ptr(), h * w * 3, w * 3, b, h, w, gray.data_ptr(), _lib.current_stream()), "dcx_bgr2gray")
     return gray

@@ -118,6 +118,30 @@ def synthetic_state_dict(kind: str, seed: int, n_ids: int = 16) -> StateDict:
     return sd
 
 
+def diverse_ids_bias_shift(ids_logits: np.ndarray, loc_argmax: np.ndarray, n_ids: int, k: int = 16, iters: int = 400):
+    """Per-class shift of ``convDb.bias[0:n_ids]`` that makes the ``k`` strongest firing cells carry as many DISTINCT ids as
+    possible.  Random-init ids heads (net.py:48 ``convDb``) let one or two classes win every cell, so fixtures built on them
+    exercise the 17-way arg-max on near-constant winners; this equalises, per class, the best margin over the dust-bin among the
+    cells the class wins (damped fixed-point iteration, best iterate kept).
+
+    ids_logits (n_ids+1, ...cells) and loc_argmax (...cells) of ONE weight set on some frames -- whoever calls this decides whose
+    logits they are (oracle/make_golden.py: the reference's).  Returns (shift float32 [n_ids], distinct ids among the top k)."""
+    live = (np.asarray(loc_argmax).reshape(-1) != 64)
+    z = np.asarray(ids_logits, dtype=np.float64).reshape(n_ids + 1, -1)[:, live]
+    mz = z[:n_ids] - z[n_ids][None]
+    b = -mz.max(1)
+    best_d, best_b = -1, b.copy()
+    for _ in range(iters):
+        zz = mz + b[:, None]
+        win, m = zz.argmax(0), zz.max(0)
+        d = len(set(win[np.argsort(-m, kind="stable")[:k]].tolist()))
+        if d > best_d:
+            best_d, best_b = d, b.copy()
+        top = np.array([m[win == c].max() if (win == c).any() else m.min() for c in range(n_ids)])
+        b = b - 0.15 * (top - np.median(top))
+    return (best_b - best_b.mean()).astype(np.float32), int(best_d)
+
+
 def state_dict_sha256(sd: StateDict, kind: str, n_ids: int = 16) -> str:
     h = hashlib.sha256()
     for k in state_dict_keys(kind, n_ids):

@@ -45,23 +45,36 @@ def workload_label(batch: int, height: int, width: int, world: int, fixed_k: int
     return base + " (custom shape, not a BASELINE config)"
 
 
-def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: int = 16, per_frame: int = 16) -> W.StateDict:
-    """Returns a copy of ``sd_dc`` whose ``convDb.bias[n_ids]`` makes ``per_frame * B`` cells fire on ``frames_dev``
-    (HIP detector logits -> host numpy; the (k-th, k+1-th) largest non-dust-bin margins bracket the shift)."""
+def _logits_on(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: int):
+    """HIP detector logits of the frames as host numpy: (loc arg-max (B,Hc,Wc), ids logits (B,n_ids+1,Hc,Wc))."""
     det = dcModel(n_ids, sd_dc, dev)
     loc_parts, ids_parts = [], []
     for i in range(0, frames_dev.shape[0], 32):          # chunked: logits of 32 high-resolution frames are ~200 MB
         out = det.forward_u8(frames_dev[i:i + 32])
-        loc_parts.append(out["loc"].argmax(1).cpu().numpy())
+        loc_parts.append(out["loc"].cpu().numpy().argmax(1))     # numpy on the host: no stock-PyTorch device operator in this package
         ids_parts.append(out["ids"].cpu().numpy())
-    la, ids = np.concatenate(loc_parts), np.concatenate(ids_parts)
+    del det
+    return np.concatenate(loc_parts), np.concatenate(ids_parts)
+
+
+def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: int = 16, per_frame: int = 16,
+                      diverse_ids: bool = False) -> W.StateDict:
+    """Returns a copy of ``sd_dc`` whose ``convDb.bias[n_ids]`` makes ``per_frame * B`` cells fire on ``frames_dev``
+    (HIP detector logits -> host numpy; the (k-th, k+1-th) largest non-dust-bin margins bracket the shift).
+
+    ``diverse_ids``: first equalise ``convDb.bias[0:n_ids]`` per class (``weights.diverse_ids_bias_shift``) so that the firing
+    cells carry all the ids of the board instead of the one or two a random-init ids head lets win everywhere."""
+    sd = {k_: v.copy() for k_, v in sd_dc.items()}
+    k = per_frame * frames_dev.shape[0]
+    la, ids = _logits_on(sd, frames_dev, dev, n_ids)
+    if diverse_ids:
+        shift, _ = W.diverse_ids_bias_shift(np.moveaxis(ids, 1, 0), la, n_ids, k)
+        sd["convDb.bias"][:n_ids] = (sd["convDb.bias"][:n_ids] + shift).astype(np.float32)
+        la, ids = _logits_on(sd, frames_dev, dev, n_ids)      # the detector's own logits with the shifted biases (not ids + shift)
     m = ids[:, :n_ids].max(1) - ids[:, n_ids]
     m = np.sort(np.where(la == 64, -1e30, m).ravel())[::-1]
-    k = per_frame * frames_dev.shape[0]
     delta = np.float32((m[k - 1] + m[k]) / 2)
-    sd = {k_: v.copy() for k_, v in sd_dc.items()}
     sd["convDb.bias"][n_ids] = np.float32(sd["convDb.bias"][n_ids] + delta)
-    del det
     return sd
 
 

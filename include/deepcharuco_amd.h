@@ -58,11 +58,18 @@ size_t dcx_detector_workspace_bytes(const dcx_detector* det, int batch, int heig
 size_t dcx_refiner_workspace_bytes(const dcx_refiner* rf, int max_patches);
 
 /* ---- colour conversion: cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) call at inference.py:40 ---------
- * 8-bit BGR frames (interleaved, row pitch / frame stride in BYTES) -> dense gray u8 [B][H][W] with OpenCV's 8-bit
- * fixed-point formula gray = (1868 B + 9617 G + 4899 R + 8192) >> 14 (third-party arithmetic, not vendored in the
- * reference: "parity unpinned" for this one step).                                                */
+ * 8-bit BGR frames (interleaved, row pitch / frame stride in BYTES) -> dense gray u8 [B][H][W].  OpenCV is third-party and not
+ * vendored in the reference ("parity unpinned" for this one step); the reference pins opencv-contrib-python
+ * >= 4.6, < 4.12 (requirements.txt:5).
+ *   dcx_bgr2gray           OpenCV 4.x RGB2Gray<uchar> (imgproc/src/color.hpp: gray_shift = 15, BY15 / GY15 / RY15):
+ *                              gray = (3735 B + 19235 G + 9798 R + 16384) >> 15
+ *   dcx_bgr2gray_legacy14  the older 14-bit form (B2Y / G2Y / R2Y, yuv_shift; in 4.x only 16-bit images and YUV use it):
+ *                              gray = (1868 B + 9617 G + 4899 R + 8192) >> 14
+ * The two differ by one level on ~0.26 % of colour pixels and never on gray-replicated input.                          */
 int dcx_bgr2gray(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
                  uint8_t* d_gray, void* stream);
+int dcx_bgr2gray_legacy14(const uint8_t* d_bgr, long frame_stride, int pitch, int batch, int height, int width,
+                          uint8_t* d_gray, void* stream);
 
 /* ---- pre-processing ------------------------------------------------------------------
  * pre_bgr_image models/model_utils.py:46-50:  out = (float(g) - 128) / 255 (IEEE division).

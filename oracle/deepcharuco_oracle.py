@@ -36,16 +36,25 @@ def to_torch_state_dict(sd) -> TensorDict:
 
 # ---------------------------------------------------------------- host pre-processing
 
-def bgr2gray(img_bgr: np.ndarray) -> np.ndarray:
+# (cB, cG, cR, shift) of OpenCV's 8-bit RGB2Gray, by OpenCV generation.  OpenCV is third-party, un-vendored and absent
+# here (parity unpinned for this one step); the reference pins opencv-contrib-python >= 4.6, < 4.12 (requirements.txt:5).
+#   opencv4:  imgproc/src/color.hpp  gray_shift = 15, BY15 = 3735, GY15 = 19235, RY15 = 9798   (RGB2Gray<uchar>, 4.x)
+#   legacy14: imgproc/src/color.hpp  yuv_shift = 14,  B2Y = 1868,  G2Y = 9617,   R2Y = 4899    (8-bit gray before 4.x; in 4.x only
+#             16-bit images and YUV)
+BGR2GRAY_VARIANTS = {"opencv4": (3735, 19235, 9798, 15), "legacy14": (1868, 9617, 4899, 14)}
+
+
+def bgr2gray(img_bgr: np.ndarray, variant: str = "opencv4") -> np.ndarray:
     """cv2.cvtColor(img, COLOR_BGR2GRAY) call at inference.py:40.
 
-    OpenCV 8-bit path: fixed point, 14 fractional bits,
-    gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+    OpenCV 8-bit path, fixed point: gray = (B*cB + G*cG + R*cR + (1 << (shift-1))) >> shift; default = the 4.x
+    constants the reference's requirements pin: (B*3735 + G*19235 + R*9798 + 16384) >> 15.
     """
+    cb, cg, cr, shift = BGR2GRAY_VARIANTS[variant]
     b = img_bgr[..., 0].astype(np.int32)
     g = img_bgr[..., 1].astype(np.int32)
     r = img_bgr[..., 2].astype(np.int32)
-    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+    return ((b * cb + g * cg + r * cr + (1 << (shift - 1))) >> shift).astype(np.uint8)
 
 
 def pre_bgr_image(image: np.ndarray) -> np.ndarray:

@@ -174,6 +174,17 @@ def calibrate_dustbin(dc, sd_dc, frame_u8, n_ids, target):
     return float(new_bias)
 
 
+def equalise_ids(dc, sd_dc, frame_u8, n_ids, target):
+    """Per-class shift of convDb.bias[0:n_ids] (weights.diverse_ids_bias_shift on the REFERENCE's logits) so that the `target`
+    strongest cells of this frame carry many distinct ids (net.py:48,76-77; model_utils.py:72-77)."""
+    x = torch.tensor(O.pre_bgr_image(frame_u8))
+    loc, ids = dc.infer_image(x)
+    shift, _ = W.diverse_ids_bias_shift(ids[0].numpy(), loc.argmax(1)[0].numpy(), n_ids, target)
+    sd_dc["convDb.bias"][:n_ids] = (sd_dc["convDb.bias"][:n_ids] + shift).astype(np.float32)
+    with torch.no_grad():
+        dc.model.convDb.bias[:n_ids] = torch.from_numpy(sd_dc["convDb.bias"][:n_ids].copy())
+
+
 CASES = [
     # name, weight seed, frame kind, frame seed, H, W, target K, keep full logits
     dict(name="tiny_noise_64x96", wseed=3, kind="noise", fseed=5, H=64, W=96, K=6, full=True),
@@ -182,6 +193,9 @@ CASES = [
     dict(name="board_480x640", wseed=7, kind="board", fseed=2, H=480, W=640, K=16, full=False),
     # BASELINE configs[4] resolution; K forced to exactly 16 by the top-16 non-dust-bin margins (calibrate_dustbin)
     dict(name="board4_960x1280", wseed=91, kind="board4", fseed=900, H=960, W=1280, K=16, full=False),
+    # ids head equalised per class on the reference's logits: >= 12 of the 16 ids fire on this one frame (the other fixtures'
+    # random-init ids heads fire 1-3 distinct ids); full logits kept so the 17-way arg-max is checked on diverse winners
+    dict(name="diverse_ids_240x320", wseed=7, kind="board", fseed=2, H=240, W=320, K=16, full=True, diverse=True),
 ]
 N_IDS = 16
 
@@ -205,6 +219,8 @@ def main():
         sd_rn = W.synthetic_state_dict("refinenet", c["wseed"] + 1)
         dc, rn = ref_models(ref_net, ref_rn, sd_dc, sd_rn, N_IDS)
         frame = W.synthetic_frames(c["kind"], c["fseed"], 1, c["H"], c["W"])[0]
+        if c.get("diverse"):
+            equalise_ids(dc, sd_dc, frame, N_IDS, c["K"])
         dust_bias = calibrate_dustbin(dc, sd_dc, frame, N_IDS, c["K"])
         tsd_dc, tsd_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
 
@@ -215,6 +231,8 @@ def main():
         la, ia = ref_mu.pred_argmax(loc, ids, N_IDS)
         kpts, ids_found = ref_mu.pred_to_keypoints(loc, ids, N_IDS)
         assert kpts.shape[0] == c["K"], (name, kpts.shape)
+        if c.get("diverse"):
+            assert len(set(ids_found.tolist())) >= 12, (name, ids_found)
         patches = ref_mu.extract_patches(x, kpts)
         with torch.no_grad():
             heat = rn(patches[:, None])
@@ -254,6 +272,8 @@ def main():
             meta=json.dumps(dict(name=name, wseed=c["wseed"], kind=c["kind"], fseed=c["fseed"],
                                  H=c["H"], W=c["W"], n_ids=N_IDS, K=c["K"])),
             dust_bias=np.float32(dust_bias),
+            convDb_bias=sd_dc["convDb.bias"].astype(np.float32).copy(),       # the whole ids-head bias the case ran with
+            distinct_ids=np.array(len(set(ids_found.tolist()))),
             sha_dc=W.state_dict_sha256(sd_dc, "detector", N_IDS),
             sha_rn=W.state_dict_sha256(sd_rn, "refinenet"),
             sha_frame=W.frames_sha256(frame),
@@ -294,10 +314,22 @@ def main():
               f"min margins loc {fx['loc_margin'].min():.2e} ids {fx['ids_margin'].min():.2e} "
               f"heat {fx['heat_margin'].min():.2e}; oracle == reference")
 
-    # BGR -> gray restatement on a colour image (cv2 absent: parity unpinned, formula only)
+    # BGR -> gray restatement on colour pixels (cv2 absent: parity unpinned, formulas only).  `gray` = the OpenCV 4.x 8-bit
+    # formula (15-bit constants; the range the reference pins), `gray_legacy14` = the older 14-bit one; `bgr_differ` are pixels
+    # on which the two DISAGREE (gray-replicated input can never tell them apart), with both answers.
     rng = np.random.default_rng(99)
     bgr = rng.integers(0, 256, (16, 24, 3), dtype=np.uint8)
-    np.savez_compressed(os.path.join(outdir, "bgr2gray_formula.npz"), bgr=bgr, gray=O.bgr2gray(bgr))
+    pool = rng.integers(0, 256, (400000, 3), dtype=np.uint8)
+    dif = pool[O.bgr2gray(pool, "opencv4") != O.bgr2gray(pool, "legacy14")]
+    assert 500 < dif.shape[0] < 2000, dif.shape            # ~0.26 % of random colour pixels
+    dif = dif[:512].reshape(16, 32, 3)
+    # hand-checked anchors: (B,G,R) -> 15-bit / 14-bit
+    assert int(O.bgr2gray(np.array([[[255, 0, 0]]], np.uint8))[0, 0]) == (255 * 3735 + 16384) >> 15 == 29
+    assert int(O.bgr2gray(np.array([[[0, 255, 0]]], np.uint8))[0, 0]) == (255 * 19235 + 16384) >> 15 == 150
+    assert int(O.bgr2gray(np.array([[[0, 0, 255]]], np.uint8))[0, 0]) == (255 * 9798 + 16384) >> 15 == 76
+    np.savez_compressed(os.path.join(outdir, "bgr2gray_formula.npz"), bgr=bgr, gray=O.bgr2gray(bgr),
+                        gray_legacy14=O.bgr2gray(bgr, "legacy14"), bgr_differ=dif, gray_differ=O.bgr2gray(dif),
+                        gray_differ_legacy14=O.bgr2gray(dif, "legacy14"))
 
     # solve_pnp (inference.py:15-29): the REFERENCE's function is called with a recording cv2.solvePnP; the fixture holds
     # the arguments it handed to OpenCV for several boards (square 5x5, the demo's 5x5 at another scale, non-square 4x7 /

@@ -10,7 +10,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
-CASES = ["tiny_noise_64x96", "noise_240x320", "board_240x320", "board_480x640", "board4_960x1280"]
+CASES = ["tiny_noise_64x96", "noise_240x320", "board_240x320", "board_480x640", "board4_960x1280", "diverse_ids_240x320"]
 
 
 def pytest_configure(config):
@@ -39,6 +39,8 @@ class GoldenCase:
         m = self.meta
         self.n_ids = m["n_ids"]
         self.sd_dc = W.synthetic_state_dict("detector", m["wseed"], m["n_ids"])
+        if "convDb_bias" in self.fx:          # the whole ids-head bias (per-class equalisation of the diverse-ids case)
+            self.sd_dc["convDb.bias"] = self.fx["convDb_bias"].astype(np.float32).copy()
         self.sd_dc["convDb.bias"][m["n_ids"]] = self.fx["dust_bias"]
         self.sd_rn = W.synthetic_state_dict("refinenet", m["wseed"] + 1)
         self.frame = W.synthetic_frames(m["kind"], m["fseed"], 1, m["H"], m["W"])[0]

@@ -6,7 +6,9 @@ rank; with >= 8 GPUs visible pass backend "nccl").  Modes:
 
   cfg4   every rank runs `infer_batches_sharded` on 1,024 frames of 320x240 (128 per rank = the per-GPU load of
          configs[3]), two batches in flight, then on a ragged 1,021-frame batch (128 x5 + 127 x3);
-  cfg5   32 frames of 1280x960 with exactly 16 corners each, kmax = 16 (4 per rank: configs[4] reduced 8x in batch only).
+  cfg5   32 frames of 1280x960 with exactly 16 corners each, kmax = 16 (4 per rank: configs[4] reduced 8x in batch only);
+  cfg5full   configs[4] at its full size: 256 frames of 1280x960 (32 per rank, 12.6 GB of workspace per rank), exactly 16
+         corners in every frame, two batches in flight.
 
 Rank 0 compares frames of EVERY rank's shard (first, last and two inner frames; for the ragged batch the frames on both
 sides of every shard boundary) with the oracle and writes the verdict.  Frame i of a batch depends only on (kind, seed + i),
@@ -102,14 +104,18 @@ def main():
                            results_returned=[len(res_a), len(res_b), len(res_r)], frames_checked=checked, corners_checked=corners,
                            mismatched=int(bad), mismatched_per_rank=per_rank,
                            mean_corners_per_frame=float(np.mean(counts)), max_corners=int(max(counts)))
-    elif mode == "cfg5":
-        per, h, w, kmax = 4, 960, 1280, 16
+    elif mode in ("cfg5", "cfg5full"):
+        per, h, w, kmax = (32 if mode == "cfg5full" else 4), 960, 1280, 16      # cfg5full: 8 x 32 = 256 frames = configs[4] itself
         n = per * world
         calib = torch.from_numpy(W.synthetic_frames("board4", SEED, 8, h, w)).to(dev)
         sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), calib, dev)
+        del calib
         dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
-        pick = lambda r: WL.select_fixed_k_frames("board4", SEED + 100000 * (r + 1), per, h, w, 16, dc, dev, chunk=8)[0]
-        mine = pick(rank)
+        seed_of = lambda r: SEED + 100000 * (r + 1)
+        mine, kept = WL.select_fixed_k_frames("board4", seed_of(rank), per, h, w, 16, dc, dev, chunk=8 if per == 4 else 32,
+                                                 max_candidates=20000)
+        kept_all = [None] * world
+        dist.all_gather_object(kept_all, [int(k) for k in kept])       # candidate numbers every rank kept (frame = f(kind, seed + j))
         batch = np.zeros((n, h, w), np.uint8)
         batch[rank * per:(rank + 1) * per] = mine
         batch2 = np.zeros((n, h, w), np.uint8)                         # second batch in flight: the shard's frames rotated by one
@@ -121,20 +127,22 @@ def main():
             checked = corners = bad = 0
             per_rank, ks = [], []
             for r in range(world):
-                fr = pick(r)                                           # same kernels, same weights -> same selection as rank r made
                 nbad = 0
-                for j in (0, per - 1):
-                    e = O.infer_image(None, 16, t_dc, t_rn, gray=fr[j])
+                for j in sorted({0, per // 2 - 1, per - 1}):
+                    fr = W.synthetic_frames("board4", seed_of(r) + kept_all[r][j], 1, h, w)[0]     # the frame rank r selected as its j-th
+                    e = O.infer_image(None, 16, t_dc, t_rn, gray=fr)
                     nbad += not same(res_a[r * per + j], e)
                     ks.append(0 if e.ndim == 1 else e.shape[0])
+                    corners += ks[-1]
                     checked += 1
                 nbad += int(not same(res_b[r * per + 1], res_a[r * per + 0])) + int(not same(res_b[r * per + 0], res_a[r * per + per - 1]))
-                corners += sum(ks[-2:])
                 per_rank.append(int(nbad))
                 bad += nbad
             verdict.update(frames=n, height=h, width=w, kmax=kmax, frames_checked=checked, corners_checked=corners,
                            corners_per_frame_seen=sorted(set(ks)), mismatched=int(bad), mismatched_per_rank=per_rank,
-                           all_frames_have_16=bool(all(a.ndim == 2 and a.shape[0] == 16 for a in res_a)))
+                           candidates_drawn_per_rank=[max(k) + 1 for k in kept_all],
+                           all_frames_have_16=bool(all(a.ndim == 2 and a.shape[0] == 16 for a in res_a)
+                                                   and all(a.ndim == 2 and a.shape[0] == 16 for a in res_b)))
     else:
         raise SystemExit(f"unknown mode {mode}")
     if rank == 0:

@@ -373,6 +373,35 @@ def test_infer_image_vs_golden(dev, golden):
         assert kp2.dtype == np.int64 and np.array_equal(kp2, fx["final_norn"])
 
 
+def test_fused_tail_on_diverse_ids_hundreds_of_cells(dev):
+    """The fused detector tail (1x1 heads + 65-/17-way arg-max + dust-bin rule, csrc/dcx_tail.hip) on DIVERSE winners: the
+    diverse-ids weight set with the dust-bin bias lowered so that hundreds of cells per frame fire with all 16 ids, four frames,
+    through infer_batch vs the live oracle; the per-class counts are reported.  A channel-order slip in the ids wave that kept a
+    dominant class would pass the other fixtures (1-3 distinct ids) but not this."""
+    from conftest import GoldenCase
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    case = GoldenCase("diverse_ids_240x320")
+    sd = {k: v.copy() for k, v in case.sd_dc.items()}
+    sd["convDb.bias"][16] -= np.float32(1.5)
+    frames = np.concatenate([case.frame[None], W.synthetic_frames("board", 31, 2, 240, 320), W.synthetic_frames("noise", 32, 1, 240, 320)])
+    dc, rn = lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(case.sd_rn, dev))
+    got = infer_batch(frames, 16, dc, rn, kmax=1200)
+    t_dc, t_rn = O.to_torch_state_dict(sd), O.to_torch_state_dict(case.sd_rn)
+    hist = np.zeros(16, np.int64)
+    bad = 0
+    for b in range(len(frames)):
+        exp = O.infer_image(None, 16, t_dc, t_rn, gray=frames[b])
+        hist += np.bincount(exp[:, 2].astype(int), minlength=16)
+        if got[b].shape != exp.shape or not np.array_equal(got[b][:, 2], exp[:, 2]):
+            bad += 1                                                    # ids column first: the point of this test
+        elif not np.array_equal(got[b], exp):
+            bad += 1
+    _report("diverse_ids/fused_tail", dict(frames=len(frames), corners=int(hist.sum()), per_id=hist.tolist(), mismatched_frames=bad))
+    assert hist.sum() > 300 and (hist > 0).sum() >= 14 and bad == 0
+
+
 def test_no_corner_returns_empty_array(dev, golden_tiny):
     from deepcharuco_amd.inference import infer_image, infer_image_staged
     from deepcharuco_amd.models.net import dcModel, lModel
@@ -643,8 +672,12 @@ def test_hazard_soak_repeated_runs_are_bit_identical(dev):
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
     d = torch.from_numpy(frames).to(dev)
 
+    counts_all = unpack_results(infer_batch_device(d, 16, dc, rn, 64).cpu().numpy(), len(frames), 64, True)[1]
+    busiest = int(np.argmax(counts_all))      # bs=1 soaks a frame that FIRES (round 3 soaked frame 0: no corners, RefineNet idle)
+
     def sha(b):
-        packed = infer_batch_device(d[:b], 16, dc, rn, 64).cpu().numpy()
+        lo = busiest if b == 1 else 0
+        packed = infer_batch_device(d[lo:lo + b], 16, dc, rn, 64).cpu().numpy()
         res, counts = unpack_results(packed, b, 64, True)
         h = hashlib.sha256(counts.tobytes())
         for r in res:
@@ -656,6 +689,7 @@ def test_hazard_soak_repeated_runs_are_bit_identical(dev):
         distinct = {first} | {sha(b)[0] for _ in range(reps - 1)}
         report[f"bs{b}"] = dict(runs=reps, corners=corners, distinct_results=len(distinct))
         assert len(distinct) == 1, f"bs={b}: {len(distinct)} different results in {reps} runs"
+        assert corners > 0, f"bs={b}: the soaked batch fires no corner -- the RefineNet half would be idle"
     x = torch.from_numpy(np.stack([O.pre_bgr_image(f) for f in frames[:32]])).to(dev)
     l0 = dc.model.forward(x)
     for _ in range(20):
@@ -665,14 +699,36 @@ def test_hazard_soak_repeated_runs_are_bit_identical(dev):
 
 
 def test_bgr2gray_device_kernel_equals_the_fixed_point_formula(dev):
+    """dcx_bgr2gray (OpenCV 4.x 8-bit constants, 15 fractional bits) and dcx_bgr2gray_legacy14 vs the oracle's integer formulas:
+    shapes with ragged widths, 2.1 M random colour triples (incl. the ~0.26 % on which the two variants disagree), the committed
+    differing pixels, and ALL 16.7 M (B, G, R) triples of the 8-bit cube."""
     from deepcharuco_amd.imgproc import bgr2gray_device
     rng = np.random.default_rng(3)
-    for shape in ((2, 37, 53, 3), (1, 240, 320, 3), (8, 10, 3)):
+    for shape in ((2, 37, 53, 3), (1, 240, 320, 3), (8, 10, 3), (3, 700, 1000, 3)):
         bgr = rng.integers(0, 256, shape, dtype=np.uint8)
-        got = bgr2gray_device(torch.from_numpy(bgr).to(dev)).cpu().numpy()
-        assert got.shape == shape[:-1] and np.array_equal(got, O.bgr2gray(bgr))
+        d_bgr = torch.from_numpy(bgr).to(dev)
+        for v in ("opencv4", "legacy14"):
+            got = bgr2gray_device(d_bgr, v).cpu().numpy()
+            assert got.shape == shape[:-1] and np.array_equal(got, O.bgr2gray(bgr, v)), (shape, v)
+    differ = int((O.bgr2gray(bgr, "opencv4") != O.bgr2gray(bgr, "legacy14")).sum())
+    assert 0.001 * bgr[..., 0].size < differ < 0.005 * bgr[..., 0].size          # the last shape: 2.1 M triples, ~5,500 differ
+    d = np.load(os.path.join(REPO, "tests", "golden", "bgr2gray_formula.npz"))
+    dd = torch.from_numpy(d["bgr_differ"]).to(dev)
+    assert np.array_equal(bgr2gray_device(dd).cpu().numpy(), d["gray_differ"])
+    assert np.array_equal(bgr2gray_device(dd, "legacy14").cpu().numpy(), d["gray_differ_legacy14"])
+    # the whole 8-bit colour cube: (256, 65536, 3)
+    ax = np.arange(256, dtype=np.uint8)
+    cube = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1).reshape(256, 65536, 3)
+    d_cube = torch.from_numpy(cube).to(dev)
+    n_dif = 0
+    for v in ("opencv4", "legacy14"):
+        assert np.array_equal(bgr2gray_device(d_cube, v).cpu().numpy(), O.bgr2gray(cube, v)), v
+    n_dif = int((O.bgr2gray(cube, "opencv4") != O.bgr2gray(cube, "legacy14")).sum())
+    _report("bgr2gray", dict(cube_triples=int(cube.shape[0] * cube.shape[1]), variants_differ_on=n_dif, random_triples_differ=differ))
     edge = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
-    assert np.array_equal(bgr2gray_device(torch.from_numpy(edge).to(dev)).cpu().numpy(), O.bgr2gray(edge))
+    assert bgr2gray_device(torch.from_numpy(edge).to(dev)).cpu().numpy().tolist() == [[255, 0, 29, 150, 76]]
+    with pytest.raises(ValueError):
+        bgr2gray_device(d_bgr, "opencv2")
 
 
 def test_hipgraph_replay_equals_eager_launches(dev, golden_tiny):
@@ -853,20 +909,30 @@ def test_deterministic_mode_runs_the_direct_family(dev):
 
 
 def test_colour_bgr_input_through_the_gpu_path(dev, golden_tiny):
-    """A real colour image (the fixtures replicate gray x3): infer_image converts with bgr2gray and must equal the oracle
-    fed with the oracle's own bgr2gray; when OpenCV is importable the formula is also checked against cv2 itself."""
+    """A real colour image (the fixtures replicate gray x3) that contains pixels on which OpenCV's 4.x and pre-4.x 8-bit
+    BGR->gray constants DISAGREE: infer_image converts on its own (cv2 when importable, else the device kernel) and must equal
+    the oracle fed with the oracle's bgr2gray of the matching variant."""
     from deepcharuco_amd.inference import infer_image
-    from deepcharuco_amd.imgproc import bgr2gray
+    from deepcharuco_amd import imgproc
     dc, rn = _models(golden_tiny, dev)
     rng = np.random.default_rng(77)
     base = W.synthetic_frames("noise", 5, 1, 64, 96)[0].astype(np.int16)
     bgr = np.clip(np.stack([base + rng.integers(-40, 41, base.shape), base + rng.integers(-8, 9, base.shape),
                             base + rng.integers(-40, 41, base.shape)], axis=2), 0, 255).astype(np.uint8)
-    assert np.array_equal(bgr2gray(bgr), O.bgr2gray(bgr)) and not np.array_equal(O.bgr2gray(bgr), bgr[..., 1])
+    # plant the committed differing pixels (16 x 32) into a corner of the image
+    d = np.load(os.path.join(REPO, "tests", "golden", "bgr2gray_formula.npz"))
+    bgr[:16, :32] = d["bgr_differ"]
+    variant = imgproc.bgr2gray_variant_of_opencv(imgproc._opencv().__version__) if imgproc._opencv() else imgproc.DEFAULT_BGR2GRAY
+    gray = O.bgr2gray(bgr, variant)
+    assert int((gray != O.bgr2gray(bgr, "legacy14" if variant == "opencv4" else "opencv4")).sum()) >= 512
+    assert np.array_equal(imgproc.bgr2gray(bgr), gray) and not np.array_equal(gray, bgr[..., 1])
     kp, img = infer_image(bgr, 16, dc, rn, device="cuda")
-    exp = O.infer_image(bgr, 16, O.to_torch_state_dict(golden_tiny.sd_dc), O.to_torch_state_dict(golden_tiny.sd_rn))
+    exp = O.infer_image(None, 16, O.to_torch_state_dict(golden_tiny.sd_dc), O.to_torch_state_dict(golden_tiny.sd_rn), gray=gray)
     assert img is bgr and kp.shape == exp.shape and np.array_equal(kp, exp)
     assert exp.ndim == 2 and exp.shape[0] > 0
+    # the graph-captured device conversion (what infer_image replays when cv2 is absent) on the same image
+    got = imgproc.bgr2gray_device(torch.from_numpy(bgr).to(dev)).cpu().numpy()
+    assert np.array_equal(got, O.bgr2gray(bgr, "opencv4"))
 
 
 @pytest.mark.parametrize("n_ids", [8, 24, 40])

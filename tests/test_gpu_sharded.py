@@ -78,6 +78,15 @@ def test_world8_cfg5_reduced_every_rank_checked(tmp_path):
     assert v["mismatched"] == 0 and v["mismatched_per_rank"] == [0] * 8 and v["frames_checked"] >= 16
 
 
+def test_world8_cfg5_full_size_every_rank_checked(tmp_path):
+    """BASELINE configs[4] at its FULL size: 256 frames of 1280x960 over eight ranks (32 each; 8 x 12.6 GB of workspace on the
+    one 288 GB GPU), exactly 16 corners in every frame, kmax = 16, two batches in flight; three frames of EVERY rank's shard vs the
+    oracle."""
+    v = _launch8("cfg5full", tmp_path, timeout=1500)
+    assert v["world"] == 8 and v["frames"] == 256 and v["all_frames_have_16"] and v["corners_per_frame_seen"] == [16]
+    assert v["mismatched"] == 0 and v["mismatched_per_rank"] == [0] * 8 and v["frames_checked"] == 24 and v["corners_checked"] == 24 * 16
+
+
 def test_two_ranks_on_one_gpu_gloo_real_kernels(tmp_path):
     v = _launch("gloo", 2, tmp_path)
     assert v["world"] == 2 and v["split"] == [[0, 6], [6, 11]]

@@ -127,7 +127,19 @@ def test_unpack_results_sorting_and_dtypes():
 def test_bgr2gray_host():
     from deepcharuco_amd.imgproc import bgr2gray
     d = np.load(os.path.join(REPO, "tests", "golden", "bgr2gray_formula.npz"))
-    assert np.array_equal(bgr2gray(d["bgr"]), d["gray"])
+    from deepcharuco_amd import imgproc
+    from oracle import deepcharuco_oracle as O
+    assert imgproc.BGR2GRAY_VARIANTS == O.BGR2GRAY_VARIANTS and imgproc.DEFAULT_BGR2GRAY == "opencv4"
+    for v, key, keyd in (("opencv4", "gray", "gray_differ"), ("legacy14", "gray_legacy14", "gray_differ_legacy14")):
+        assert np.array_equal(imgproc.bgr2gray_fixed_point(d["bgr"], v), d[key])
+        assert np.array_equal(imgproc.bgr2gray_fixed_point(d["bgr_differ"], v), d[keyd])
+    if imgproc._opencv():      # with OpenCV installed bgr2gray IS cv2.cvtColor: it must agree with the variant of that version
+        v = imgproc.bgr2gray_variant_of_opencv(imgproc._opencv().__version__)
+        assert np.array_equal(bgr2gray(d["bgr_differ"]), imgproc.bgr2gray_fixed_point(d["bgr_differ"], v))
+    else:
+        assert np.array_equal(bgr2gray(d["bgr"]), d["gray"]) and np.array_equal(bgr2gray(d["bgr_differ"]), d["gray_differ"])
+    assert [imgproc.bgr2gray_variant_of_opencv(x) for x in ("4.6.0", "4.11.0.86", "3.4.2", "2.4.13", "weird")] == \
+        ["opencv4", "opencv4", "legacy14", "legacy14", "opencv4"]
 
 
 def test_checkpoint_reader_never_unpickles_code_silently(tmp_path):
@@ -241,9 +253,13 @@ def test_bgr2gray_formula_against_opencv_when_available():
     this test pins the fixed-point restatement against it on a random colour image."""
     cv2 = pytest.importorskip("cv2")
     from oracle import deepcharuco_oracle as O
+    from deepcharuco_amd.imgproc import bgr2gray_variant_of_opencv
+    variant = bgr2gray_variant_of_opencv(cv2.__version__)       # 4.x (what the reference pins): 15-bit constants; before: 14-bit
     rng = np.random.default_rng(5)
     bgr = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
-    assert np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY), O.bgr2gray(bgr))
+    assert np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY), O.bgr2gray(bgr, variant))
+    d = np.load(os.path.join(GOLDEN, "bgr2gray_formula.npz"))   # pixels on which the two variants disagree
+    assert np.array_equal(cv2.cvtColor(d["bgr_differ"], cv2.COLOR_BGR2GRAY), O.bgr2gray(d["bgr_differ"], variant))
 
 
 def test_shard_range_partition():
@@ -415,3 +431,35 @@ def test_missing_native_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libdeepcharuco_amd.so"))
     with pytest.raises(RuntimeError, match="no CPU / stock-PyTorch fallback"):
         _lib.lib()
+
+
+def test_bench_gpus_n_from_a_bare_shell_refuses_rccl_without_enough_gpus():
+    """`python bench.py --gpus 2` with no launcher variables: bench.py is its own launcher; with fewer GPUs than ranks and the
+    default backend (RCCL) it exits 2 with a clear message -- never a silent gloo run, never 'launch with torch.distributed.run'."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the refusal does not apply")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "torch.distributed.run" not in r.stderr
+
+
+def test_diverse_ids_fixture_fires_every_id():
+    """tests/golden/diverse_ids_240x320.npz (reference run, make_golden.py): the 16 firing cells carry >= 12 distinct ids, so the
+    17-way ids arg-max and the id column of the result are exercised on diverse winners (the random-init heads fire 1-3 ids)."""
+    fx = np.load(os.path.join(GOLDEN, "diverse_ids_240x320.npz"))
+    ids = fx["ids_found"]
+    assert ids.shape == (16,) and len(set(ids.tolist())) >= 12 and int(fx["distinct_ids"]) == len(set(ids.tolist()))
+    assert np.array_equal(np.sort(fx["final_rn"][:, 2]), np.sort(ids.astype(np.float64)))
+    # the solver itself on synthetic logits: 3 classes dominate -> after the shift the top-16 carry >= 12 ids
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((17, 40, 30)) + np.array([3.0, 2.5, 2.0] + [0.0] * 14)[:, None, None]
+    la = rng.integers(0, 65, (40, 30))
+    before = z[:16].reshape(16, -1)[:, la.ravel() != 64]
+    top = np.argsort(-(before.max(0) - z[16].ravel()[la.ravel() != 64]))[:16]
+    assert len(set(before.argmax(0)[top].tolist())) <= 6
+    shift, d = W.diverse_ids_bias_shift(z, la, 16, 16)
+    assert shift.dtype == np.float32 and shift.shape == (16,) and d >= 12 and abs(float(shift.mean())) < 1e-5

@@ -22,8 +22,20 @@ def test_bgr2gray_formula():
     from conftest import GOLDEN
     d = np.load(os.path.join(GOLDEN, "bgr2gray_formula.npz"))
     assert np.array_equal(O.bgr2gray(d["bgr"]), d["gray"])
+    assert np.array_equal(O.bgr2gray(d["bgr"], "legacy14"), d["gray_legacy14"])
+    # pixels on which the OpenCV 4.x (15-bit) and the older 14-bit constants DISAGREE: each variant gives its own answer
+    dif = d["bgr_differ"]
+    assert dif.shape == (16, 32, 3) and not (d["gray_differ"] == d["gray_differ_legacy14"]).any()
+    assert np.abs(d["gray_differ"].astype(int) - d["gray_differ_legacy14"].astype(int)).max() == 1
+    assert np.array_equal(O.bgr2gray(dif), d["gray_differ"]) and np.array_equal(O.bgr2gray(dif, "legacy14"), d["gray_differ_legacy14"])
+    # default = the generation the reference pins (opencv-contrib-python >= 4.6, < 4.12): gray_shift 15, 3735 / 19235 / 9798
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [10, 200, 30]]], np.uint8)
+    assert O.bgr2gray(px).tolist() == [[29, 150, 76, 255, (10 * 3735 + 200 * 19235 + 30 * 9798 + 16384) >> 15]]
     g = np.arange(256, dtype=np.uint8).reshape(16, 16)
-    assert np.array_equal(O.bgr2gray(np.repeat(g[..., None], 3, 2)), g)   # gray in -> same gray out
+    for v in O.BGR2GRAY_VARIANTS:
+        cb, cg, cr, sh = O.BGR2GRAY_VARIANTS[v]
+        assert cb + cg + cr == 1 << sh
+        assert np.array_equal(O.bgr2gray(np.repeat(g[..., None], 3, 2), v), g)   # gray in -> same gray out, either variant
 
 
 def test_detector_stages(golden):

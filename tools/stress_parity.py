@@ -41,12 +41,24 @@ def oracle_chunk(spec):
     x = torch.from_numpy(np.stack([O.pre_bgr_image(f) for f in frames]))          # (n,1,h,w)
     t_dc = O.to_torch_state_dict(sd_dc)
     loc, ids = O.detector_forward(t_dc, x)
-    # dust-bin bias so that ~12 cells per frame fire (same rule as workload.calibrate_dustbin, on the oracle's logits)
     la = loc.argmax(1)
+    if cid % 3 == 1:
+        # a third of the chunks: ids-head biases equalised per class on the oracle's logits, so the firing cells carry all 16 ids
+        shift, _ = W.diverse_ids_bias_shift(np.moveaxis(ids.numpy(), 1, 0), la.numpy(), N_IDS, 12 * n)
+        sd_dc["convDb.bias"][:N_IDS] = (sd_dc["convDb.bias"][:N_IDS] + shift).astype(np.float32)
+        loc, ids = O.detector_forward(O.to_torch_state_dict(sd_dc), x)
+        la = loc.argmax(1)
+    # dust-bin bias so that ~12 cells per frame fire (same rule as workload.calibrate_dustbin, on the oracle's logits) ...
     m = (ids[:, :N_IDS].max(1).values - ids[:, N_IDS])
     m = torch.where(la == 64, torch.tensor(-1e30), m).flatten().sort(descending=True).values
     k = 12 * n
-    delta = np.float32((m[k - 1] + m[k]) / 2)
+    if cid % 2 == 0:
+        delta = np.float32((m[k - 1] + m[k]) / 2)
+    else:
+        # ... every second chunk: NOT the midpoint of the gap -- the threshold lands within +-2e-4 of a cell's own margin, so that
+        # the fire / no-fire decision is sampled where it is close
+        rng = np.random.default_rng(cid)
+        delta = np.float32(float(m[k - 1 + int(rng.integers(-3, 4))]) + rng.uniform(-2e-4, 2e-4))
     sd_dc["convDb.bias"][N_IDS] = np.float32(sd_dc["convDb.bias"][N_IDS] + delta)
     t_dc = O.to_torch_state_dict(sd_dc)
     loc, ids = O.detector_forward(t_dc, x)
@@ -66,7 +78,7 @@ def oracle_chunk(spec):
         heat_margin.append((top.values[:, 0] - top.values[:, 1]).numpy())
     cat = lambda l, dt: np.concatenate(l).astype(dt) if l else np.zeros((0,), dt)
     path = os.path.join(SHM, f"dcx_stress_{os.getpid()}_{cid}.npz")
-    np.savez(path, frames=frames, loc=loc.numpy(), ids=ids.numpy(), dust_bias=np.float32(sd_dc["convDb.bias"][N_IDS]),
+    np.savez(path, frames=frames, loc=loc.numpy(), ids=ids.numpy(), convDb_bias=sd_dc["convDb.bias"].astype(np.float32),
              kp=np.concatenate(kp_all).astype(np.int64) if kp_all else np.zeros((0, 2), np.int64), kp_frame=cat(fr_idx, np.int64),
              heat_idx=cat(heat_idx, np.int64), heat_margin=cat(heat_margin, np.float32), sub=np.array(sub),
              finals=np.array(finals, dtype=object), wseed=wseed, cid=cid)
@@ -93,7 +105,8 @@ def main():
     edges = torch.tensor(EDGES[1:-1], device=dev)
     nb = len(EDGES) - 1
     zero = lambda: {"cells": np.zeros(nb, np.int64), "disagree": np.zeros(nb, np.int64)}
-    stats = {"loc": zero(), "ids": zero(), "heat": zero()}
+    stats = {"loc": zero(), "ids": zero(), "heat": zero(), "fire": zero()}
+    ids_hist = np.zeros(N_IDS, np.int64)
     per_res = {}
     frames_done = e2e_frames = e2e_bad = corners = cells_decided_differently = 0
     t0 = time.time()
@@ -105,7 +118,7 @@ def main():
             frames = z["frames"]
             n, h, w = frames.shape
             sd_dc = W.synthetic_state_dict("detector", int(z["wseed"]), N_IDS)
-            sd_dc["convDb.bias"][N_IDS] = z["dust_bias"]
+            sd_dc["convDb.bias"] = z["convDb_bias"].astype(np.float32).copy()      # equalised ids biases (a third of the chunks) + dust-bin
             sd_rn = W.synthetic_state_dict("refinenet", int(z["wseed"]) + 1)
             det, ref = dcModel(N_IDS, sd_dc, dev), RefineNet(sd_rn, dev)
             d_frames = torch.from_numpy(frames).to(dev)
@@ -126,6 +139,12 @@ def main():
             o_la, o_ia, g_la, g_ia = o_loc.argmax(1), o_ids.argmax(1), got["loc"].argmax(1), got["ids"].argmax(1)
             fire_o, fire_g = (o_la != 64) & (o_ia != N_IDS), (g_la != 64) & (g_ia != N_IDS)
             cells_decided_differently += int(((fire_o != fire_g) | (fire_o & ((o_la != g_la) | (o_ia != g_ia)))).sum())
+            # fire / no-fire by the distance of the oracle's decision from its threshold (cells whose loc head fires)
+            fm = (o_ids[:, :N_IDS].max(1).values - o_ids[:, N_IDS]).abs()[o_la != 64]
+            bucket = torch.bucketize(fm, edges, right=True)
+            stats["fire"]["cells"] += torch.bincount(bucket, minlength=nb).cpu().numpy()
+            stats["fire"]["disagree"] += torch.bincount(bucket[(fire_o != fire_g)[o_la != 64]], minlength=nb).cpu().numpy()
+            ids_hist += torch.bincount(o_ia[fire_o], minlength=N_IDS + 1)[:N_IDS].cpu().numpy()
             # RefineNet on the oracle's key-points (every 4th frame)
             kp, kf = z["kp"], z["kp_frame"]
             if kp.shape[0]:
@@ -154,6 +173,9 @@ def main():
     out = {"frames": frames_done, "seconds": round(time.time() - t0, 1), "per_resolution": per_res,
            "max_abs_logit_diff": max(r["max_abs_logit_diff"] for r in per_res.values()),
            "cells_whose_decision_differs": cells_decided_differently,
+           "firing_cells_per_id": ids_hist.tolist(),
+           "weight_sets": "61 seeds; a third of the chunks with the ids-head biases equalised per class (all 16 ids fire); every second chunk "
+                          "with the dust-bin threshold within +-2e-4 of a cell's own margin (fire/no-fire sampled where it is close)",
            "end_to_end": {"frames": e2e_frames, "corners": corners, "mismatched_frames": e2e_bad},
            "buckets": label,
            "histogram": {k: {"decided": v["cells"].tolist(), "hip_disagrees": v["disagree"].tolist()} for k, v in stats.items()}}
@@ -162,6 +184,10 @@ def main():
         json.dump(out, f, indent=1)
     print(f"\n{frames_done} frames, max |HIP - oracle| logit {out['max_abs_logit_diff']:.3e}; "
           f"cells decided differently: {cells_decided_differently}; end to end: {e2e_bad} of {e2e_frames} frames differ ({corners} corners)")
+    print("firing cells per id:", ids_hist.tolist())
+    print(f"{'|fire margin| (ids max - dust-bin)':>36s} | {'cells':>12s} {'fire/no-fire differs':>22s}")
+    for i in range(nb):
+        print(f"{label[i]:>36s} | {stats['fire']['cells'][i]:12d} {stats['fire']['disagree'][i]:22d}")
     print(f"{'oracle top-2 margin':>22s} | {'loc cells':>12s} {'differ':>7s} | {'ids cells':>12s} {'differ':>7s} | {'heat-maps':>10s} {'differ':>7s}")
     for i in range(nb):
         print(f"{label[i]:>22s} | {stats['loc']['cells'][i]:12d} {stats['loc']['disagree'][i]:7d} | {stats['ids']['cells'][i]:12d} "
