@@ -20,10 +20,10 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_ATOL = 5e-5     # |logit| <= ~6
 XY_ATOL = 1e-4        # px, north-star tolerance (we get exact equality)
-MARGIN = 4e-5         # arg-max must match exactly wherever the reference's top-2 gap exceeds this: >= 2x the largest |HIP - oracle|
-                      # logit difference measured over 20,256 frames / 27 M arg-max decisions (1.81e-5, profiles/r03_stress_parity.txt:
-                      # 0 disagreements above 1e-5, 25 below it); cells under the margin are COUNTED and their agreement
-                      # reported in gpurun_out/parity_report.json (SURVEY.md H1 policy; rounds 1 / 2 used 1e-4 / 1e-5)
+MARGIN = 1e-5         # HARD gate: arg-max must match exactly wherever the reference's top-2 gap exceeds this.  The stress run (20 k frames,
+                      # 27 M decisions, profiles/r0*_stress_parity.txt) has 0 disagreements above 1e-5 (25 below it), so nothing looser is
+                      # needed; cells under the margin are COUNTED and their agreement reported in gpurun_out/parity_report.json
+MARGIN_REPORT = 4e-5  # >= 2x the largest |HIP - oracle| logit difference measured (1.81e-5): reporting threshold only
 
 REPORT = {}
 
@@ -323,9 +323,10 @@ def test_detector_logits_and_argmax_vs_golden(dev, golden):
     la, ia = la[0].cpu().numpy(), ia[0].cpu().numpy()
     safe_loc = fx["loc_margin"] > MARGIN
     near = int((~safe_loc).sum())
+    near_report = int((~(fx["loc_margin"] > MARGIN_REPORT)).sum())
     mism_all = int((la != fx["loc_argmax"]).sum())
     near_ids = int((~(fx["ids_margin"] > MARGIN)).sum())
-    _report(f"detector_argmax/{golden.name}", dict(cells=int(la.size), margin=MARGIN, near_tie_cells_loc=near, near_tie_cells_ids=near_ids,
+    _report(f"detector_argmax/{golden.name}", dict(cells=int(la.size), margin=MARGIN, near_tie_cells_loc=near, cells_under_4e5_loc=near_report, near_tie_cells_ids=near_ids,
                                                    loc_mismatch_total=mism_all,
                                                    ids_mismatch_total=int((ia != fx["ids_argmax"]).sum())))
     assert np.array_equal(la[safe_loc], fx["loc_argmax"].astype(np.int64)[safe_loc])
