@@ -335,8 +335,11 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     cpu = cpu_baseline(oracle, name, frames) if want_cpu_baseline else None     # also fills the oracle's result cache
     pick = list(range(min(n_check, B)))
-    if os.environ.get("DCX_BENCH_CORRUPT_PARITY") and res_local and res_local[0].ndim == 2:   # test hook: prove that the gate gates
-        res_local[0] = res_local[0].copy(); res_local[0][0, 0] += 1.0
+    if os.environ.get("DCX_BENCH_CORRUPT_PARITY"):   # test hook: prove that the gate gates (first checked frame that has corners)
+        for b in pick:
+            if res_local[b].ndim == 2:
+                res_local[b] = res_local[b].copy(); res_local[b][0, 0] += 1.0
+                break
     checks = [((name, 0, b), frames[b], res_local[b]) for b in pick]
     if dist_on:
         # frames of EVERY other rank out of the gathered buffer (2 per rank; the last rank gets as many as rank 0 / 2)

@@ -78,13 +78,27 @@ struct DcxWino2hCfg {
     // in 16-lane groups (16 consecutive tiles of one cq); with the plain layout those land on few of the sixteen 16-B slots of a
     // 256-B bank row (4-way conflicts at TW = 16: 35 % of the kernel's LDS cycles).  Per tile shape:
     //   TW = 16 (8 tiles per row, a group = two tile rows): pitch 20, one slot of shift on every second row PAIR -> 16 distinct slots;
-    //   TW = 20 (10 tiles per row): pitch 23 and the same shift: at most 2 lanes per slot (plain layout: 3) -- ten even slots of one
-    //           tile row cannot fit the eight even residues, so 2-way is the floor for this lane order;
+    //   TW = 20 (10 tiles per row): rounds 2-3 used pitch 23 + the same shift (2 lanes per slot at best: 17 % conflict cycles); see PLANAR below;
     //   8x8 maps, G = 2 (4 tiles per row, a group = one whole map): pitch 12, one slot of shift on every second PAIR of row pairs
     //           -> the four tile rows start at residues 0, 8, 1, 9: 16 distinct slots.
-    static constexpr int RP = TW_ == 16 ? RW + 2 : TW_ == 20 ? RW + 1 : TW_ == 8 ? RW + 2 : RW + 1;
+    //   TW = 20 since round 4: EVEN / ODD COLUMN PLANES.  Every lane of a transform read wants the same column parity (column
+    //           2 tx + j), so inside a parity plane consecutive tiles sit on consecutive slots; plane row pitch 13 puts the three tile
+    //           rows of a lane group 10 and 4 slots apart (mod 16): with the hardware's ds_read_b128 lane groups (tiles {0-3, 12-15,
+    //           20-27} / {4-11, 16-19, 28-31}) all 16 slots of a group differ; odd plane at +108 (= 4 mod 8) keeps the raw tile's
+    //           ds_write_b128 (8 consecutive columns) conflict-free.  tools/lds_sim.py: 17.0 % of the kernel's LDS cycles -> 2.2 %.
+    static constexpr bool PLANAR = TW_ == 20;
+    static constexpr int PRP = 13, PODD = 108, PCQ = 216;  // planar: plane row pitch, offset of the odd-column plane, slots per channel quad
+    static constexpr int RP = TW_ == 16 ? RW + 2 : TW_ == 20 ? PRP : TW_ == 8 ? RW + 2 : RW + 1;
     static constexpr int ROW_SHIFT = TW_ == 8 ? 2 : 1;     // ROWOFF(hy) = (hy >> ROW_SHIFT) & 1
-    static constexpr int RAW_LDS = G * CQC * HH * RP;      // slot RP - 1 of row 0 (shift 0, RW <= RP - 1) is free -> dump slot
+    static constexpr int RAW_LDS = PLANAR ? G * CQC * PCQ : G * CQC * HH * RP;      // slot RP - 1 of row 0 is free in every layout -> dump slot
+    // LDS slot (float4 index inside the raw tile) of raw pixel (hy, hx) of channel quad cq of image img
+    __host__ __device__ static constexpr int raw_slot(int img, int cq, int hy, int hx) {
+        return PLANAR ? (img * CQC + cq) * PCQ + (hx & 1) * PODD + hy * PRP + (hx >> 1)
+                      : ((img * CQC + cq) * HH + hy) * RP + hx + ((hy >> ROW_SHIFT) & 1);
+    }
+    // offset of column + j relative to an EVEN column's slot in the same row (the transform reads columns 2 tx .. 2 tx + 3)
+    __host__ __device__ static constexpr int col_step(int j) { return PLANAR ? (j & 1) * PODD + (j >> 1) : j; }
+    static_assert(!PLANAR || (HH * PRP <= PODD && PODD + HH * PRP <= PCQ && (RW + 1) / 2 < PRP), "planar raw tile does not fit its planes");
     static constexpr int VPLANE = CQC * 32;                // float4 per position: [cq][tile]
     static constexpr int LDS_FLOAT4 = 16 * VPLANE;         // one transformed buffer (32 KB)
     static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_LDS) * 16 + 256;     // + output-transform table
@@ -164,7 +178,6 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
 
     // ---- staging: raw tile ---------------------------------------------------------------------------------------
     constexpr int RP = C::RP;
-    auto rowoff = [](int row) { return (row >> C::ROW_SHIFT) & 1; };
     int r_hyx[ITER_R], r_slot[ITER_R];       // (hy << 16 | hx) of the thread's raw pixels (G > 1: the image of the group) and their LDS slots
     unsigned r_rel[ITER_R];
     const unsigned in_img_stride = (unsigned)a.in_cq_total * (unsigned)(a.hin * a.win);   // float4 between images
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         r_hyx[k] = hy << 16 | hx;
         const int prow = ((hy - a.pad) >> a.ups) + a.pad, pcol = ((hx - a.pad) >> a.ups) + a.pad;
         r_rel[k] = idx < C::RAW ? ((unsigned)img * in_img_stride + (unsigned)((cq * a.hin + prow) * a.win + pcol)) * 16u : 0x80000000u;
-        r_slot[k] = idx < C::RAW ? ((img * CQC + cq) * C::HH + hy) * RP + hx + rowoff(hy) : RP - 1;
+        r_slot[k] = idx < C::RAW ? C::raw_slot(img, cq, hy, hx) : RP - 1;
         if (C::G > 1) {
             // a grouped tile always starts at pixel (0, 0) of its images: the zero-padding predicate is a per-piece constant
             const int ly = hy - a.pad, lx = hx - a.pad;
@@ -194,12 +207,12 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     const int x_tile = min(tid & 31, C::NTILES - 1);
     const int x_img = x_tile / C::TPI, x_t = x_tile - x_img * C::TPI;
     const int x_ty = x_t / TX, x_tx = x_t - x_ty * TX;
-    const int x_src = ((x_img * CQC + x_cq) * C::HH + 2 * x_ty) * RP + 2 * x_tx;   // raw slot of the window's top-left pixel (before the row shift)
     // rows of the half-piece, branch-free: first xi = row A - row B, second xi = row B + sgn * row C
     //   h = 0: xi 0 = d0 - d2 (A = 0, B = 2), xi 1 = d1 + d2 (C = 1, sgn = +1);  h = 1: xi 2 = d2 - d1 (A = 2, B = 1), xi 3 = d1 - d3 (C = 3, sgn = -1)
     const int x_ia = x_h ? 2 : 0, x_ib = x_h ? 1 : 2, x_ic = x_h ? 3 : 1;
-    const int x_ra = x_src + x_ia * RP + rowoff(2 * x_ty + x_ia), x_rb = x_src + x_ib * RP + rowoff(2 * x_ty + x_ib),
-              x_rc = x_src + x_ic * RP + rowoff(2 * x_ty + x_ic);
+    // raw slots of the window's left pixel (column 2 tx, always even) in the three rows this half needs
+    const int x_ra = C::raw_slot(x_img, x_cq, 2 * x_ty + x_ia, 2 * x_tx), x_rb = C::raw_slot(x_img, x_cq, 2 * x_ty + x_ib, 2 * x_tx),
+              x_rc = C::raw_slot(x_img, x_cq, 2 * x_ty + x_ic, 2 * x_tx);
     const float x_sg = x_h ? -1.f : 1.f;
     const dcx_f32x2 x_sgn = {x_sg, x_sg};
     const int x_dst = (8 * x_h) * VPLANE + x_cq * 32 + x_tile;         // + local position * VPLANE
@@ -239,10 +252,10 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     auto xform_event = [&](float4* vbuf, int x) {
         if (x == 0) {
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) { xa[cidx] = sR[x_ra + cidx]; xb[cidx] = sR[x_rb + cidx]; }
+            for (int cidx = 0; cidx < 4; ++cidx) { xa[cidx] = sR[x_ra + C::col_step(cidx)]; xb[cidx] = sR[x_rb + C::col_step(cidx)]; }
         } else if (x == 1) {
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) xc[cidx] = sR[x_rc + cidx];
+            for (int cidx = 0; cidx < 4; ++cidx) xc[cidx] = sR[x_rc + C::col_step(cidx)];
         } else if (x >= 3) {
             const int ms = x - 3;
             if (ms > 0) vbuf[x_dst + (ms - 1) * VPLANE] = xv;

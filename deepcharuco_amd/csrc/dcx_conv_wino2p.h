@@ -166,7 +166,16 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
     const int x_img = x_tile / C::TPI, x_t = x_tile - x_img * C::TPI;
     const int x_ty = x_t / TX, x_tx = x_t - x_ty * TX;
     const int x_src = ((x_img * CQC + wm) * C::HH + 2 * x_ty) * RP + 2 * x_tx;
-    const dcx_f32x2* sR2 = reinterpret_cast<const dcx_f32x2*>(sR);
+    // Relaxed atomic 8-byte loads: hipcc otherwise fuses neighbouring plain reads into ds_read2_b64, which costs 8 LDS cycles per
+    // pair instead of 2 + 2 and is banked modulo 32 in 16-lane groups -- the raw tile's row shift is built for ds_read_b64 (32-lane
+    // groups, 64 banks).  Round 3's counters: 15-16 % of this kernel's LDS cycles were bank conflicts, all of them from the fused
+    // reads (tools/lds_sim.py reproduces the counters of every conv kernel).  An atomic load is never fused and, unlike a volatile
+    // one, keeps its LDS address space (the volatile form compiles to flat_load).
+    const unsigned long long* sR2 = reinterpret_cast<const unsigned long long*>(sR);
+    auto ld2 = [&](int idx) {
+        const unsigned long long v = __hip_atomic_load(sR2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return dcx_f32x2{__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
+    };
     const int x_r0 = 2 * (x_src + rowoff(2 * x_ty)) + x_hb, x_r1 = 2 * (x_src + RP + rowoff(2 * x_ty + 1)) + x_hb,
               x_r2 = 2 * (x_src + 2 * RP + rowoff(2 * x_ty + 2)) + x_hb;      // float2 index of d[r][0]; d[r][s] at + 2 s
     const int x_dst = 2 * (wm * 32 + x_tile) + x_hb;                            // float2 index; + 2 * pos * VPLANE
@@ -195,10 +204,10 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
         dcx_f32x2* v2 = reinterpret_cast<dcx_f32x2*>(vbuf);
         if (x == 0) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) { xd0[s] = sR2[x_r0 + 2 * s]; xd1[s] = sR2[x_r1 + 2 * s]; }
+            for (int s = 0; s < 3; ++s) { xd0[s] = ld2(x_r0 + 2 * s); xd1[s] = ld2(x_r1 + 2 * s); }
         } else if (x == 1) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) xd2[s] = sR2[x_r2 + 2 * s];
+            for (int s = 0; s < 3; ++s) xd2[s] = ld2(x_r2 + 2 * s);
         } else if (x == 2) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) xd0[s] = dcx_pk_sub(xd0[s], xd1[s]);            // t[0][s]
