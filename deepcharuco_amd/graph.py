@@ -34,7 +34,11 @@ class GraphedPipeline:
         det = deepc.model if hasattr(deepc, "model") else deepc
         ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
         self.dev = det.device
-        self.dust_bin_ids, self.deepc, self.refinenet = dust_bin_ids, deepc, refinenet
+        self.dust_bin_ids = dust_bin_ids
+        # weak references to the inner models: the pipeline lives in a cache ON the detector, a strong reference back would be a
+        # cycle that only the cyclic GC frees (~25 MB of workspace + pinned buffers per shape); with weak ones the graphs die with
+        # the model by reference count
+        self._det, self._ref = weakref.ref(det), (None if ref is None else weakref.ref(ref))
         self.batch, self.h, self.w, self.kmax, self.bgr = batch, height, width, kmax, bgr
         L = _lib.lib()
         shape = (batch, height, width, 3) if bgr else (batch, height, width)
@@ -61,6 +65,22 @@ class GraphedPipeline:
                 self._enqueue()
         self._in_np = self.pin_in.numpy()
         self._out_np = self.pin_out.numpy()
+
+    @property
+    def deepc(self):
+        det = self._det()
+        if det is None:
+            raise RuntimeError("the detector this graph was captured with has been destroyed")
+        return det
+
+    @property
+    def refinenet(self):
+        if self._ref is None:
+            return None
+        ref = self._ref()
+        if ref is None:
+            raise RuntimeError("the RefineNet this graph was captured with has been destroyed")
+        return ref
 
     def _enqueue(self) -> None:
         self.dev_in.copy_(self.pin_in, non_blocking=True)
@@ -105,36 +125,50 @@ def graphs_usable() -> bool:
 
 def clear_graph_cache(deepc=None) -> None:
     """Drop the captured graphs (and their pinned / workspace buffers) of one detector, or of all of them."""
-    victims = []                        # destroyed AFTER the lock is released: a pipeline may hold the last reference to a model,
-    with _cache_lock:                   # whose destructor calls back into this module
-        if deepc is not None:
-            det = deepc.model if hasattr(deepc, "model") else deepc
-            caches = [getattr(det, "_graph_cache", None)]
-        else:
-            caches = list(_caches)
-        for c in caches:
-            if c:
-                victims.extend(c.values())
-                c.clear()
-    del victims
+    with _graph_lock:                   # destruction (hipGraphExecDestroy, hipFree of the workspace) never overlaps a replay / capture
+        victims = []                    # ... but happens outside _cache_lock; lock order is always _graph_lock -> _cache_lock
+        with _cache_lock:
+            if deepc is not None:
+                det = deepc.model if hasattr(deepc, "model") else deepc
+                caches = [getattr(det, "_graph_cache", None)]
+            else:
+                caches = list(_caches)
+            for c in caches:
+                if c:
+                    victims.extend(c.values())
+                    c.clear()
+        del victims
+
+
+def drop_graphs_of_detector(det) -> None:
+    """Called when a detector releases its C handle: its graphs hold pointers into the freed weights."""
+    with _graph_lock:
+        victims = []
+        with _cache_lock:
+            cache = getattr(det, "_graph_cache", None)
+            if cache:
+                victims = list(cache.values())
+                cache.clear()
+        del victims
 
 
 def drop_graphs_of_refiner(ref) -> None:
     """Called when a RefineNet releases its C handle (reload / ``to(device)`` / destruction): graphs captured with it hold
     pointers into the freed weights."""
-    victims = []
-    with _cache_lock:
-        for c in list(_caches):
-            for k in [k for k in c if k[0] is not None and k[0][0] == id(ref)]:
-                victims.append(c.pop(k, None))
-    del victims
+    with _graph_lock:
+        victims = []
+        with _cache_lock:
+            for c in list(_caches):
+                for k in [k for k in c if k[0] is not None and k[0][0] == id(ref)]:
+                    victims.append(c.pop(k, None))
+        del victims
 
 
 def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int, bgr: bool,
                     kmax: int = DEFAULT_KMAX) -> Optional[GraphedPipeline]:
     """One graph per (model pair, shape, library mode) for ``infer_image``, shared by all threads.  The cache lives ON the detector
-    object (a small LRU), so graphs die with the model instead of pinning it in a module-global table, and a re-allocated
-    model can never alias a cached graph of a freed one."""
+    object (a small LRU) and its pipelines refer back to the models weakly, so graphs die with the model (by reference count)
+    instead of pinning it in a module-global table, and a re-allocated model can never alias a cached graph of a freed one."""
     det = deepc.model if hasattr(deepc, "model") else deepc
     ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
     key = (None if ref is None else (id(ref), ref.handle.value), dust_bin_ids, height, width, bgr, kmax,
@@ -148,8 +182,10 @@ def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int
             p = cache.pop(key, None)
         if p is None:
             p = GraphedPipeline(dust_bin_ids, deepc, refinenet, 1, height, width, kmax, bgr)
+        evicted = []
         with _cache_lock:
             while len(cache) >= _CACHE_MAX:
-                cache.pop(next(iter(cache)))
+                evicted.append(cache.pop(next(iter(cache))))
             cache[key] = p
+        del evicted                                           # destroyed under _graph_lock, outside _cache_lock
     return p

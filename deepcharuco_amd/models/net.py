@@ -64,11 +64,9 @@ class dcModel:
 
     def _release(self):
         if self._handle is not None:
-            cache = getattr(self, "_graph_cache", None)      # hipGraphs captured with this handle's weights (graph.py)
-            if cache:
-                victims = list(cache.values())
-                cache.clear()
-                del victims
+            if getattr(self, "_graph_cache", None):          # hipGraphs captured with this handle's weights (graph.py)
+                from ..graph import drop_graphs_of_detector
+                drop_graphs_of_detector(self)                # under the graph lock, then the cache lock (same order as everywhere)
             _lib.lib().dcx_detector_destroy(self._handle)
             self._handle = None
 

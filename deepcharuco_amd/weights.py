@@ -130,13 +130,20 @@ def diverse_ids_bias_shift(ids_logits: np.ndarray, loc_argmax: np.ndarray, n_ids
     z = np.asarray(ids_logits, dtype=np.float64).reshape(n_ids + 1, -1)[:, live]
     mz = z[:n_ids] - z[n_ids][None]
     b = -mz.max(1)
-    best_d, best_b = -1, b.copy()
+    best_key, best_b, best_d = (-1, -1.0), b.copy(), 0
     for _ in range(iters):
         zz = mz + b[:, None]
         win, m = zz.argmax(0), zz.max(0)
-        d = len(set(win[np.argsort(-m, kind="stable")[:k]].tolist()))
-        if d > best_d:
-            best_d, best_b = d, b.copy()
+        order = np.argsort(-m, kind="stable")
+        topk = order[:k]
+        d = len(set(win[topk].tolist()))
+        # The fixed point of this iteration sits ON decision boundaries (a class's best cell is one it barely wins, and the k-th / k+1-th
+        # margins meet), which would plant exact ties into the fixtures.  Keep the iterate with the most distinct ids whose firing
+        # cells are decided by a healthy margin: class top-2 gap and distance of the k-th / (k+1)-th margins, both capped at 1e-3.
+        part = np.partition(zz[:, topk], n_ids - 2, axis=0)
+        gap = float(min((part[n_ids - 1] - part[n_ids - 2]).min(), m[order[k - 1]] - m[order[min(k, len(order) - 1)]], 1e-3))
+        if (d, gap) > best_key:
+            best_key, best_b, best_d = (d, gap), b.copy(), d
         top = np.array([m[win == c].max() if (win == c).any() else m.min() for c in range(n_ids)])
         b = b - 0.15 * (top - np.median(top))
     return (best_b - best_b.mean()).astype(np.float32), int(best_d)
