@@ -56,6 +56,10 @@ struct DcxConvArgs {
     int cout_real;         // un-padded output channels (profiling only)
     int tiles_x, tiles_y;
     int xcd_walk;          // set by the launcher: XCD-aware item walk
+    int ct_outer;          // set by the launcher (2-D Winograd kernels): work items ordered cout tile OUTERMOST (image inside), so that
+                           // with the XCD-aware walk an XCD works on one or two cout tiles at a time -- for layers whose transformed
+                           // weights (16 x cin x cout x 4 B: 4.2 MB for the fused 512-cout heads) do not fit an XCD's 4 MB L2 next to
+                           // the activations.  Same items, same bits; only the order changes.
 };
 
 // Picks a tile configuration for (ho, wo, cout_pad, pool, epi, ks) and launches.

@@ -152,8 +152,13 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         DcxItem it;
         it.tx = wi % a.tiles_x; wi /= a.tiles_x;
         it.ty = wi % a.tiles_y; wi /= a.tiles_y;
-        it.ct = wi % n_ct;
-        it.n = wi / n_ct;
+        if (C::G == 1 && a.ct_outer) {
+            it.n = wi % n_eff;
+            it.ct = wi / n_eff;
+        } else {
+            it.ct = wi % n_ct;
+            it.n = wi / n_ct;
+        }
         it.ph = 0;
         return it;
     };
@@ -521,6 +526,12 @@ static int dcx_conv_wino2h_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const long resident = (occ_env == 1 ? 1L : 2L) * dcx_device_cu_count();
     const long blocks = items < resident ? items : resident;
     a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
+    {   // cout tile outermost where the layer's transformed weights would otherwise thrash the XCDs' L2 (DCX_CT_OUTER=0/1 forces it)
+        static int force = -2;
+        if (force == -2) { const char* e = getenv("DCX_CT_OUTER"); force = e ? atoi(e) : -1; }
+        const size_t w_bytes = (size_t)16 * a.cin * a.cout_pad * 4;
+        a.ct_outer = force >= 0 ? force : (a.xcd_walk && a.n_limit == nullptr && a.cout_pad / C::COUT_TILE >= 4 && w_bytes > (size_t)(2u << 20)) ? 1 : 0;
+    }
     static bool attr_set[DCX_MAX_DEVICES] = {};
     const int dev_i = dcx_current_device();
     if (!attr_set[dev_i]) {
