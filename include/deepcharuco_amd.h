@@ -175,7 +175,8 @@ int dcx_c4_to_nchw(const float* d_c4, int n, int c, int h, int w, float* d_nchw,
 /* ---- instrumentation: per-stage device time of the last dcx_infer_batch() ---------------
  * When enabled, the pipeline records hipEvents on its stream around each stage; after the
  * stream has been synchronised by the caller, dcx_last_timings() returns milliseconds:
- * [0] detector conv stack, [1] decode+table+gather, [2] RefineNet, [3] total.              */
+ * [0] detector conv stack, [1] fused tail (1x1 heads + arg-max) + compaction + patch table, [2] RefineNet INCLUDING the patch
+ * gather (its conv1a reads the 24x24 windows out of the frames since round 3), [3] total.  */
 int dcx_set_timing(int enabled);
 int dcx_get_timing(void);            /* 1 while per-stage timing is on (callers that capture hipGraphs must launch eagerly then) */
 int dcx_last_timings(float* h_ms4);

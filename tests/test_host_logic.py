@@ -463,3 +463,24 @@ def test_diverse_ids_fixture_fires_every_id():
     assert len(set(before.argmax(0)[top].tolist())) <= 6
     shift, d = W.diverse_ids_bias_shift(z, la, 16, 16)
     assert shift.dtype == np.float32 and shift.shape == (16,) and d >= 12 and abs(float(shift.mean())) < 1e-5
+
+
+def test_lds_bank_model_of_the_raw_tile_layouts():
+    """tools/lds_sim.py restates the LDS banking rules of gfx950 (lane groups / bank modulus per instruction) and the raw-tile
+    layouts of the Winograd kernels.  It reproduced round 3's SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE per kernel to the digit
+    (8x16: 2.8 %, 6x20: 17.0 %, 16-tile items: 3.8 %), which is how round 4's layouts were found; this pins the model's verdict on
+    them: the planar 6x20 tile is at 2.2 % (measured: 2.24 %), no transform read of any layout conflicts."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_sim", os.path.join(REPO, "tools", "lds_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    pct = lambda r: 100.0 * sum(v[1] for v in r.values()) / sum(v[0] for v in r.values())
+    old_6x20 = sim.wino2h(6, 20)                                         # rounds 2-3: pitch 23 + row-pair shift
+    planar = sim.wino2h(6, 20, slot_of=lambda img, cq, hy, hx: cq * 216 + (hx & 1) * 108 + hy * 13 + (hx >> 1))
+    assert abs(pct(old_6x20) - 17.0) < 0.1 and old_6x20["xform_read"][1] == 192
+    assert pct(planar) < 2.5 and planar["xform_read"][1] == 0 and planar["load_b"][1] == 0
+    for r in (sim.wino2h(8, 16), sim.wino2h(8, 8, G=2), sim.wino2h(8, 8, TB=1), sim.wino2p(8, 16), sim.wino2p(8, 8, 2)):
+        assert r["xform_read"][1] == 0 and r["load_b"][1] == 0 and r["xform_write"][1] == 0
+    # the constants the header uses for the planar tile (csrc/dcx_conv_wino2h.h)
+    src = open(os.path.join(REPO, "deepcharuco_amd", "csrc", "dcx_conv_wino2h.h")).read()
+    assert "PRP = 13, PODD = 108, PCQ = 216" in src
