@@ -185,10 +185,16 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
     if fixed_k:
-        frames, _ = WL.select_fixed_k_frames(frames_kind, seed0, B, H, Wd, fixed_k, dc, dev)
+        frames, kept = WL.select_fixed_k_frames(frames_kind, seed0, B, H, Wd, fixed_k, dc, dev, max_candidates=20000)
     else:
         frames = W.synthetic_frames(frames_kind, seed0, B, H, Wd)
     d_frames = torch.from_numpy(frames).to(dev)
+    kept_all = None
+    if fixed_k and (world > 1 or cx.force_dist):
+        # which candidate frames every rank selected (frame j of a rank = synthetic_frames(kind, its seed + kept[j])): rank 0 renders
+        # only the few frames of the other ranks it checks instead of repeating every rank's whole selection (minutes at 1280x960)
+        kept_all = [None] * world
+        dist.all_gather_object(kept_all, [int(k) for k in kept])
 
     n_i32 = packed_len(B, kmax)
     host_local = torch.empty((n_i32,), dtype=torch.int32).pin_memory()
@@ -345,12 +351,11 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         # frames of EVERY other rank out of the gathered buffer (2 per rank; the last rank gets as many as rank 0 / 2)
         for r in range(1, world):
             res_r = unpack_results(per_rank[r], B, kmax, True)[0]
-            if fixed_k:
-                fr_r, _ = WL.select_fixed_k_frames(frames_kind, FRAME_SEED + r * 100000, B, H, Wd, fixed_k, dc, dev)
-            else:
-                fr_r = W.synthetic_frames(frames_kind, FRAME_SEED + r * 100000, B, H, Wd)
             n_r = max(2, n_check // 2) if r == world - 1 else 2
-            checks += [((name, r, b), fr_r[b], res_r[b]) for b in ([0, B - 1] if n_r == 2 else pick[:n_r])]
+            for b in ([0, B - 1] if n_r == 2 else pick[:n_r]):
+                j = kept_all[r][b] if fixed_k else b
+                fr = W.synthetic_frames(frames_kind, FRAME_SEED + r * 100000 + j, 1, H, Wd)[0]     # frame b of rank r's batch
+                checks.append(((name, r, b), fr, res_r[b]))
     parity = parity_block(oracle, checks)
 
     out = {

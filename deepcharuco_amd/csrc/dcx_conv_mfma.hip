@@ -49,27 +49,18 @@ struct CfgEntry {
       &dcx_conv_wino2p_launch_cfg<DcxWino2pCfg<TH, TW, EPI, G>>,                                           \
       "dcx_conv_wino2p_kernel<DcxWino2pCfg<" #TH "," #TW "," #EPI "," #G ">>" }
 
-// Direct-kernel wave layouts:  A = 1x4 waves, 64 couts x 256 px   B = 2x2 waves, 128 couts x 128 px   C = 4x1 waves, 128 couts x 64 px
+// Direct-kernel wave layouts:  A = 1x4 waves, 64 couts x 256 px   S / P = 2x2 waves, 64 couts x 64 / 256 px
+// (Round 4 trimmed the direct family from 18 to 6 instantiations: on the default path it only runs the raw 1x1 heads; the 3x3
+//  tiles below are what deterministic mode -- the A/B reference of the Winograd families -- needs to run every layer shape, not a
+//  tuned set: the 12x20 / 6x40 / 16x16 / 10x20 / 6x18 / 8x16 / 4x1-wave variants were speed-ups of a mode no BASELINE config uses.)
 const CfgEntry kCfgs[] = {
     // ---- direct family: the 1x1 heads, deterministic mode (every layer), cin < 32
     // 3x3 + BN + ReLU
     DCX_CFG(1, 4, 2, 2, 8, 32, 3, 0, DCX_EPI_BNRELU),
-    DCX_CFG(1, 4, 2, 2, 12, 20, 3, 0, DCX_EPI_BNRELU),
-    DCX_CFG(1, 4, 2, 2, 6, 40, 3, 0, DCX_EPI_BNRELU),
-    DCX_CFG(1, 4, 2, 2, 16, 16, 3, 0, DCX_EPI_BNRELU),
-    DCX_CFG(1, 4, 2, 2, 10, 20, 3, 0, DCX_EPI_BNRELU),
-    DCX_CFG(2, 2, 2, 2, 6, 18, 3, 0, DCX_EPI_BNRELU),
-    DCX_CFG(2, 2, 2, 2, 8, 16, 3, 0, DCX_EPI_BNRELU),
-    DCX_CFG(4, 1, 1, 2, 8, 8, 3, 0, DCX_EPI_BNRELU),
     DCX_CFG(2, 2, 1, 1, 8, 8, 3, 0, DCX_EPI_BNRELU),     // S: 64 cout x 64 px, 32x32 per wave (small batches / small maps)
     // 3x3 + BN + ReLU + 2x2 max-pool
-    DCX_CFG(1, 4, 2, 2, 8, 32, 3, 1, DCX_EPI_BNRELU),
-    DCX_CFG(1, 4, 2, 2, 12, 20, 3, 1, DCX_EPI_BNRELU),
-    DCX_CFG(1, 4, 2, 2, 6, 40, 3, 1, DCX_EPI_BNRELU),
-    DCX_CFG(1, 4, 2, 2, 16, 16, 3, 1, DCX_EPI_BNRELU),
-    DCX_CFG(2, 2, 2, 2, 8, 16, 3, 1, DCX_EPI_BNRELU),
     DCX_CFG(2, 2, 1, 1, 8, 8, 3, 1, DCX_EPI_BNRELU),
-    DCX_CFG(2, 2, 1, 4, 8, 32, 3, 1, DCX_EPI_BNRELU),    // pooling window inside one lane (2x2 waves, 32 couts x 128 px per wave)
+    DCX_CFG(2, 2, 1, 4, 8, 32, 3, 1, DCX_EPI_BNRELU),    // P: pooling window inside one lane (2x2 waves, 32 couts x 128 px per wave)
     // 1x1, raw (image flattened to 1 x P by the caller)
     DCX_CFG(1, 4, 2, 2, 1, 256, 1, 0, DCX_EPI_RAW),
     // RefineNet head: 3x3 + BN + ReLU + 1x1 -> 1 channel + tile arg-max

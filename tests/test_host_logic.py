@@ -378,7 +378,7 @@ def test_conv_kernels_do_not_spill():
                     "-pragma-unroll-threshold=200000", "-S", src, "-o", out], check=True, capture_output=True)
     asm = open(out).read()
     spills = dict(re.findall(r"\.name:\s+(_Z2\ddcx_conv_\w+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", asm))
-    assert len(spills) >= 26
+    assert len(spills) >= 14
     bad = {k: v for k, v in spills.items() if int(v) != 0}
     assert not bad, f"kernels with VGPR spills: {bad}"
     # half-tile and phase Winograd kernels (two / three workgroups per CU): no scratch in the unit loops; hipcc may park a few
