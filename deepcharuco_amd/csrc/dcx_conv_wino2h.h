@@ -56,6 +56,14 @@
 #ifndef DCX_W2H_E_XFORM
 #define DCX_W2H_E_XFORM 14
 #endif
+// The two workgroups of a CU take turns at wave priority: bit DCX_PRIO_FLIP of the 100 MHz real-time clock (12: every 41 us),
+// inverted for the second-dispatched half of the grid.  Without it the SIMD arbiter prefers the OLDER workgroup, which finishes
+// its items ~16 % earlier and leaves the other one alone at the end of the launch.  Measured at bs=32 (two runs each, same box):
+// dominant kernel 0.750 -> 0.762 of peak, step 10,373 -> 10,461 fps; bit 11 / 13: +0.4 %; 0 = off.  The same rotation among the
+// phase kernel's three workgroups gained nothing.  Speed only -- no effect on the bits.
+#ifndef DCX_PRIO_FLIP
+#define DCX_PRIO_FLIP 12
+#endif
 
 template <int TH_, int TW_, bool POOL_, int G_ = 1, int TB_ = 2>
 struct DcxWino2hCfg {
@@ -322,6 +330,16 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
             else { has_next = false; cn = c; }
         }
         const int buf = u & 1;
+#if DCX_PRIO_FLIP > 0
+        {
+            // the SIMD arbiter prefers the OLDER of a CU's two workgroups, which then finishes its items ~16 % earlier and leaves the
+            // other one alone at the end: take turns instead -- priority follows a bit of the real-time clock,
+            // inverted for the second-dispatched half of the grid
+            const unsigned rt = (unsigned)__builtin_amdgcn_s_memrealtime();
+            const bool hi = (((rt >> DCX_PRIO_FLIP) & 1u) != 0u) != (blockIdx.x >= (gridDim.x >> 1));
+            if (hi) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[4 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0 && (unsigned)(u - a.probe_u0) < 20u) a.clk_probe[5 + 3 * (u - a.probe_u0)] = __builtin_amdgcn_s_memtime();
