@@ -234,7 +234,7 @@ struct DetWs {
 };
 DetWs det_layout(int n_ids, int b, int h, int w) {
     DetWs L;
-    const size_t hw = (size_t)h * w, cells = hw / 64;
+    const size_t hw = (size_t)h * w, cells = (size_t)(h / 8) * (w / 8);
     L.ids_quads = (n_ids + 1 + 3) / 4;
     size_t off = 0;
     L.buf0 = off; off = align_up(off + (size_t)b * 64 * hw * 4, 256);
@@ -284,7 +284,7 @@ extern "C" const char* dcx_error_string(int code) {
     switch (code) {
         case 0: return "ok";
         case DCX_E_ARG: return "DCX_E_ARG: null pointer or bad scalar argument";
-        case DCX_E_SHAPE: return "DCX_E_SHAPE: unsupported shape (H/W must be multiples of 8, patches 24x24, ...)";
+        case DCX_E_SHAPE: return "DCX_E_SHAPE: unsupported shape (H/W below 8, patches not 24x24, batch x kmax too large, ...)";
         case DCX_E_WS: return "DCX_E_WS: workspace too small";
         case DCX_E_NIDS: return "DCX_E_NIDS: n_ids outside [1, 62] or dust_bin outside [0, 255]";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dcx error";
@@ -366,7 +366,7 @@ int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame
                  bool with_heads, float* d_loc_nchw, float* d_ids_nchw, void* stream) {
     if (!det || !d_ws) return DCX_E_ARG;
     if ((d_frames_u8 == nullptr) == (d_images_f32 == nullptr)) return DCX_E_ARG;
-    if (batch <= 0 || height < 8 || width < 8 || (height & 7) || (width & 7)) return DCX_E_SHAPE;
+    if (batch <= 0 || height < 8 || width < 8) return DCX_E_SHAPE;      // any size >= 8: the three poolings floor (net.py:16)
     const DetWs L = det_layout(det->n_ids, batch, height, width);
     if (ws_bytes < L.total) return DCX_E_WS;
     hipStream_t s = (hipStream_t)stream;
@@ -425,7 +425,7 @@ extern "C" int dcx_detector_decode(const dcx_detector* det, int batch, int heigh
                                    int dust_bin, int kmax, int32_t* d_counts, int32_t* d_rows, int32_t* d_loc_argmax,
                                    int32_t* d_ids_argmax, void* stream) {
     if (!det || !d_ws) return DCX_E_ARG;
-    if (batch <= 0 || height < 8 || width < 8 || (height & 7) || (width & 7)) return DCX_E_SHAPE;
+    if (batch <= 0 || height < 8 || width < 8) return DCX_E_SHAPE;      // any size >= 8: the three poolings floor (net.py:16)
     const DetWs L = det_layout(det->n_ids, batch, height, width);
     const int hc = height / 8, wc = width / 8;
     const long cells = (long)hc * wc;
@@ -634,7 +634,7 @@ extern "C" int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf, c
     if (!det || !d_frames_u8 || !d_ws || !d_counts || !d_rows) return DCX_E_ARG;
     if (rf != nullptr && d_xy == nullptr) return DCX_E_ARG;
     if (kmax <= 0 || (long)batch * kmax > (1 << 22)) return DCX_E_SHAPE;
-    if (batch <= 0 || height < 8 || width < 8 || (height & 7) || (width & 7)) return DCX_E_SHAPE;
+    if (batch <= 0 || height < 8 || width < 8) return DCX_E_SHAPE;      // any size >= 8: the three poolings floor (net.py:16)
     if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)d_ws;

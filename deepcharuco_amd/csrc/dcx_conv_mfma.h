@@ -450,7 +450,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
             for (int nt = 0; nt < NT; ++nt) {
                 int sy = oy0 + qys[nt], sx = ox0 + qxs[nt];
                 bool ok = qok[nt] && sy < a.ho && sx < a.wo;
-                if (C::POOL) { ok = ok && (P4 || (l31 & 3) == 0); sy >>= 1; sx >>= 1; }
+                if (C::POOL) {      // (sy, sx) = the window's top-left pixel; MaxPool2d(2,2) floors odd sizes: the whole window must exist
+                    ok = ok && (sy | 1) < a.ho && (sx | 1) < a.wo && (P4 || (l31 & 3) == 0);
+                    sy >>= 1; sx >>= 1;
+                }
                 pix_ok[nt] = ok;
                 lane_off[nt] = ((unsigned)half * plane + (unsigned)(sy * ws + sx)) * 16u;
             }

@@ -289,7 +289,7 @@ int dcx_launch_conv_mfma(DcxConvArgs a, int ks, int pool, int epi, hipStream_t s
     if (a.in == nullptr || a.w == nullptr || a.bias == nullptr) return DCX_E_ARG;
     if (epi != DCX_EPI_HEAT && a.out == nullptr) return DCX_E_ARG;
     if (epi != DCX_EPI_RAW && (a.alpha == nullptr || a.beta == nullptr)) return DCX_E_ARG;
-    if (pool && ((a.ho | a.wo) & 1)) return DCX_E_SHAPE;
+    if (pool && (a.ho < 2 || a.wo < 2)) return DCX_E_SHAPE;      // odd sizes are fine: the pooling floors like MaxPool2d(2,2)
     // the fused-head launch must use the tiling dcx_conv_heat_tiles() sized part_val / part_idx for
     const CfgEntry* c = pick(epi == DCX_EPI_HEAT ? (1 << 20) : (a.n_hint > 0 && a.n_hint < a.n ? a.n_hint : a.n), a.cin, a.ho, a.wo, a.cout_pad, ks, pool, epi,
                              a.ups == 0 && a.pad == 1,    // grouped tiles: same-size convolutions read without up-sampling

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                     v.z = dcx_vmax(dcx_vmax(dcx_vmax(y[0].z, y[1].z), dcx_vmax(y[2].z, y[3].z)), 0.f);
                     v.w = dcx_vmax(dcx_vmax(dcx_vmax(y[0].w, y[1].w), dcx_vmax(y[2].w, y[3].w)), 0.f);
                     char* dst = obase_i + (size_t)((unsigned)((oy0 >> 1) * ws + (ox0 >> 1)) * 16u);
-                    if (okr0 && okc0) *reinterpret_cast<float4*>(dst) = v;
+                    if (okr1 && okc1) *reinterpret_cast<float4*>(dst) = v;       // MaxPool2d(2,2) floors: a window needs both rows and columns
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define DCX_E_ARG      (-1)   /* null pointer / bad scalar */
-#define DCX_E_SHAPE    (-2)   /* H or W not a multiple of 8, patch not 24x24 ... */
+#define DCX_E_SHAPE    (-2)   /* H or W below 8, patch not 24x24, capacity overflow ... */
 #define DCX_E_WS       (-3)   /* workspace too small */
 #define DCX_E_NIDS     (-4)   /* n_ids outside [1, 62] at create(); dust_bin outside [0, 255] at decode */
 

@@ -156,6 +156,8 @@ CONV_CASES = [
     ("P_ups_partial_10x12", 2, 64, 64, 10, 12, 1, 1, 0, 3, True),
     ("W2H_600_items_xcd_walk", 6, 64, 64, 96, 128, 1, 0, 0, 3, True),     # > 2 x 256 work items: persistent XCD-aware walk
     ("W2H_600_items_xcd_walk_pool", 5, 64, 128, 88, 120, 1, 0, 1, 3, True),  # partial tiles, two cout tiles, pooled
+    ("W2H_pool_odd_25x37", 2, 64, 64, 25, 37, 1, 0, 1, 3, True),          # MaxPool2d(2,2) floors: 25x37 -> 12x18
+    ("W2H_pool_odd_valid_21x19", 3, 128, 128, 23, 21, 0, 0, 1, 3, True),   # valid conv 23x21 -> 21x19 -> pool 10x9
     ("k1_raw_65", 2, 256, 65, 30, 40, 0, 0, 0, 1, False),
     ("k1_raw_17", 2, 256, 17, 6, 9, 0, 0, 0, 1, False),
 ]
@@ -970,7 +972,9 @@ def test_c_abi_error_codes(dev, golden_tiny):
     assert ok == 0
     torch.cuda.synchronize()
     assert L.dcx_detector_forward(det.handle, frames.data_ptr(), 60 * 96, 96, None, 1, 60, 96, ws.data_ptr(),
-                                  ws.numel(), None, None, None) == -2                     # H not a multiple of 8
+                                  ws.numel(), None, None, None) == 0                      # H not a multiple of 8: legal since round 4 (the poolings floor)
+    assert L.dcx_detector_forward(det.handle, frames.data_ptr(), 4 * 96, 96, None, 1, 4, 96, ws.data_ptr(),
+                                  ws.numel(), None, None, None) == -2                     # H < 8: not a single cell
     assert L.dcx_detector_forward(det.handle, frames.data_ptr(), 64 * 96, 96, None, 1, 64, 96, ws.data_ptr(), 1024,
                                   None, None, None) == -3                                 # workspace too small
     assert L.dcx_detector_forward(det.handle, None, 0, 0, None, 1, 64, 96, ws.data_ptr(), ws.numel(),
@@ -980,7 +984,7 @@ def test_c_abi_error_codes(dev, golden_tiny):
     assert L.dcx_detector_create(C.byref(h), arr, 64, 16) == -1                           # null tensors
     assert L.dcx_detector_create(C.byref(h), arr, 63, 16) == -1                           # wrong tensor count
     with pytest.raises(_lib.DcxError, match="DCX_E_SHAPE"):
-        det.forward(torch.zeros((1, 1, 60, 96), device=dev))
+        det.forward(torch.zeros((1, 1, 5, 96), device=dev))
     from deepcharuco_amd.models.refinenet import RefineNet
     rn = RefineNet(golden_tiny.sd_rn, dev)
     with pytest.raises(ValueError):
@@ -1189,12 +1193,13 @@ def test_pitched_frame_buffer_through_c_abi(dev, golden_tiny):
     assert np.array_equal(r0[0, :int(c0[0]), :2].numpy(), golden_tiny.fx["kpts"])
 
 
-@pytest.mark.parametrize("hw", [(88, 104), (136, 200), (8, 8), (24, 1024), (248, 328)])
-def test_odd_resolutions_multiples_of_8(dev, hw):
-    """Any H, W divisible by 8 is legal (the nets are fully convolutional): shapes whose maps are not
-    multiples of any tile (11x13, 17x25, 31x41 cells; a single cell; a 3-cell-high strip) through the batch path, 1 / 3 / 9
-    frames each (different launch sizes pick different tiles of the SAME family), every frame identical to the oracle and to
-    itself across batch sizes."""
+@pytest.mark.parametrize("hw", [(88, 104), (136, 200), (8, 8), (24, 1024), (248, 328), (250, 330), (243, 325), (67, 101), (9, 15), (100, 75)])
+def test_odd_resolutions(dev, hw):
+    """Any H, W >= 8 is legal, as in the reference (the nets are fully convolutional and MaxPool2d(2,2) floors odd sizes,
+    net.py:16,61-70): shapes whose maps are not multiples of any tile (11x13, 17x25, 31x41 cells; a single
+    cell; a 3-cell-high strip) and -- since round 4 -- sizes that are NOT multiples of 8 (250x330 -> 125x165 -> 62x82 -> 31x41
+    cells; odd at every level: 243x325; 67x101; 9x15; 100x75) through the batch path, 1 / 3 / 9 frames each (different launch
+    sizes pick different tiles of the SAME family), every frame identical to the oracle and to itself across batch sizes."""
     from deepcharuco_amd.inference import infer_batch
     from deepcharuco_amd.models.net import dcModel, lModel
     from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
