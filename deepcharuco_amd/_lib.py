@@ -59,6 +59,7 @@ SIGNATURES = {
     "dcx_detector_forward": (_i, [_vp, _vp, _l, _i, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "dcx_detector_decode": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dcx_pred_to_keypoints": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dcx_label_to_keypoints": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dcx_build_patch_table": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "dcx_extract_patches_u8": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "dcx_extract_patches_f32": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),

@@ -386,6 +386,30 @@ extern "C" int dcx_pred_to_keypoints(const float* d_loc, const float* d_ids, int
                              d_loc_argmax, d_ids_argmax, nullptr, (hipStream_t)stream);
 }
 
+// label_to_keypoints (model_utils.py:91-124) on caller label maps: loc / ids int64 [B][Hc][Wc] (class indices, as pred_argmax
+// returns them or as the dataset's labels hold them) -> the same ordered rows as the decode of logits: mask = ids != dust_bin,
+// x = 8 ix + loc % 8, y = 8 iy + loc / 8, in torch.nonzero's raster order.  The maps are packed to one code per cell
+// (loc | id << 8, d_codes: 4 B per cell of scratch) and compacted by the kernel the pipeline uses.
+__global__ __launch_bounds__(256) void dcx_pack_labels_kernel(const long long* __restrict__ loc, const long long* __restrict__ ids,
+                                                              long n, int32_t* __restrict__ codes, int* __restrict__ bad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long l = loc[i], d = ids[i];
+    if (l < 0 || l > 255 || d < 0 || d > 255) { if (bad) *bad = 1; codes[i] = 0; return; }
+    codes[i] = (int32_t)l | ((int32_t)d << 8);
+}
+
+extern "C" int dcx_label_to_keypoints(const long long* d_loc, const long long* d_ids, int batch, int hc, int wc, int dust_bin,
+                                      int kmax, int32_t* d_counts, int32_t* d_rows, int32_t* d_codes, int32_t* d_bad, void* stream) {
+    if (!d_loc || !d_ids || !d_counts || !d_rows || !d_codes) return DCX_E_ARG;
+    if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0) return DCX_E_SHAPE;
+    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
+    const long n = (long)batch * hc * wc;
+    hipLaunchKernelGGL(dcx_pack_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_loc, d_ids, n,
+                       d_codes, d_bad);
+    return dcx_launch_compact(d_codes, batch, hc, wc, dust_bin, kmax, d_counts, d_rows, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // patch table: exclusive scan of min(counts, kmax) over the frames of a batch (one workgroup).
 __device__ __forceinline__ void dcx_patch_table_body(const int32_t* __restrict__ counts, const int32_t* __restrict__ rows,

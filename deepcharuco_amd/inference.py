@@ -253,6 +253,8 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
     from .imgproc import _opencv
     if not isinstance(img, np.ndarray) or img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
         raise ValueError("expected a (H,W,3) uint8 BGR image")
+    if draw_pred:      # debugging aid: the reference draws the UNREFINED detections too, which only the staged path has at hand
+        return infer_image_staged(img, dust_bin_ids, deepc, refinenet, True, device)
     keypoints = None
     from .graph import graphs_usable
     if _graphs_enabled() and graphs_usable():
@@ -279,20 +281,22 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
             det, _ = _unwrap(deepc, refinenet)
             d_gray = bgr2gray_device(torch.from_numpy(np.ascontiguousarray(img)).to(det.device))
             keypoints = infer_batch(d_gray[None], dust_bin_ids, deepc, refinenet)[0]
-    if draw_pred:
-        img = _draw(img, keypoints, refined=refinenet is not None)
     return keypoints, img
 
 
 def infer_image_staged(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_pred: bool = False,
                        device="cuda"):
-    """The reference's body (inference.py:40-70) statement by statement on the mirrored functions."""
+    """The reference's body (inference.py:40-70) statement by statement on the mirrored functions, including its two drawing
+    steps: the detector's key-points in red (radius 3, with ids) before the K = 0 early-out, the refined corners in yellow
+    (radius 1) after RefineNet -- each on a copy, so ``draw_pred=True`` never touches the caller's array."""
     require_cuda(device)
     img_gray = bgr2gray(img)
     img_gray = pre_bgr_image(img_gray)
     img_gray = torch.tensor(img_gray, device=device)
     loc_hat, ids_hat = deepc.infer_image(img_gray)
     keypoints, ids_found = pred_to_keypoints(loc_hat, ids_hat, dust_bin_ids)
+    if draw_pred:
+        img = draw_inner_corners(img, keypoints.cpu().numpy(), ids_found.cpu().numpy(), radius=3, draw_ids=True, color=(0, 0, 255))
     if ids_found.shape[0] == 0:
         return np.array([]), img
     if refinenet is not None:
@@ -300,23 +304,32 @@ def infer_image_staged(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None
         keypoints, _ = refinenet.infer_patches(patches, keypoints)
     keypoints = keypoints.cpu().numpy()
     ids_found = ids_found.cpu().numpy()
+    if draw_pred and refinenet is not None:
+        img = draw_inner_corners(img, keypoints, ids_found, draw_ids=False, radius=1, color=(0, 255, 255))
     keypoints = np.array([[k[0], k[1], idx] for k, idx in sorted(zip(keypoints, ids_found), key=lambda x: x[1])])
-    if draw_pred:
-        img = _draw(img, keypoints, refined=refinenet is not None)
     return keypoints, img
 
 
-def _draw(img: np.ndarray, keypoints: np.ndarray, refined: bool) -> np.ndarray:
-    """Minimal stand-in for aruco_utils.draw_inner_corners (:135-192): circles + ids on a COPY."""
+def draw_inner_corners(img: np.ndarray, corners: np.ndarray, ids: np.ndarray, draw_ids: bool = False, radius: int = 2,
+                       color=(0, 0, 255)) -> np.ndarray:
+    """What ``infer_image(draw_pred=True)`` draws with (the reference's helper of the same name, aruco_utils.py:135-192): on a COPY
+    of the 3-channel image, a thin circle at every corner rounded to the nearest pixel (corners beyond the right / bottom edge are
+    skipped) and, if asked, the id in green beside it.  Needs OpenCV (host-side drawing is not part of the GPU path)."""
     try:
         import cv2  # type: ignore
-    except ImportError as e:  # pragma: no cover
+    except ImportError as e:
         raise ImportError("draw_pred=True needs OpenCV for drawing, which is not installed") from e
+    assert img.ndim == 3 and img.shape[-1] == 3
     out = img.copy()
-    for x, y, idx in np.asarray(keypoints).reshape(-1, 3):
-        c = (int(round(float(x))), int(round(float(y))))
-        cv2.circle(out, c, 1 if refined else 3, (0, 255, 255) if refined else (0, 0, 255), -1)
-        cv2.putText(out, str(int(idx)), c, cv2.FONT_HERSHEY_SIMPLEX, 0.3, (0, 0, 255), 1)
+    font, thickness = cv2.FONT_HERSHEY_COMPLEX_SMALL, 1
+    for corner, idx in zip(corners, ids):
+        c = np.round(corner).astype(int)
+        if c[0] > out.shape[1] or c[1] > out.shape[0]:
+            continue
+        cv2.circle(out, (int(c[0]), int(c[1])), radius=radius, color=color, thickness=thickness)
+        if draw_ids:
+            (tw, th), _ = cv2.getTextSize(str(idx), font, .5, thickness)
+            cv2.putText(out, str(idx), (int(c[0]) - tw // 2 - 7, int(c[1]) + th // 2 - 3), font, .45, (0, 255, 0), thickness)
     return out
 
 

@@ -72,6 +72,36 @@ def pred_to_keypoints(loc_hat: torch.Tensor, ids_hat: torch.Tensor, dust_bin_ids
     return r[:, 0:2].contiguous(), r[:, 2].contiguous()
 
 
+def label_to_keypoints(loc: torch.Tensor, ids: torch.Tensor, dust_bin_ids: int):
+    """model_utils.py:91-124: class-index maps (N,Hc,Wc) -- what ``pred_argmax`` returns, or a dataset label -- ->
+    (kpts (K,2) int64 (x,y), ids (K,) int64) in ``torch.nonzero``'s raster order; ``mask = ids != dust_bin_ids``,
+    ``x = 8*ix + loc % 8``, ``y = 8*iy + loc // 8``.  Device tensors only (HIP: ``dcx_label_to_keypoints``)."""
+    assert loc.ndim == 3 and ids.ndim == 3
+    dev = loc.device
+    if dev.type != "cuda" or ids.device != dev or loc.shape != ids.shape:
+        raise ValueError("label_to_keypoints expects two (N,Hc,Wc) label maps on the same GPU")
+    loc = loc.to(torch.int64).contiguous()
+    ids = ids.to(torch.int64).contiguous()
+    n, hc, wc = loc.shape
+    kmax = hc * wc
+    counts = torch.empty((n,), dtype=torch.int32, device=dev)
+    rows = torch.empty((n, kmax, 4), dtype=torch.int32, device=dev)
+    codes = torch.empty((n, kmax), dtype=torch.int32, device=dev)
+    bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().dcx_label_to_keypoints(loc.data_ptr(), ids.data_ptr(), n, hc, wc, dust_bin_ids, kmax, counts.data_ptr(),
+                                                     rows.data_ptr(), codes.data_ptr(), bad.data_ptr(), _lib.current_stream()),
+                   "dcx_label_to_keypoints")
+    cnt = counts.cpu().tolist()
+    if int(bad.cpu()[0]):
+        raise ValueError("label_to_keypoints: class indices must lie in [0, 255]")
+    parts = [rows[b, :c] for b, c in enumerate(cnt) if c > 0]
+    if not parts:
+        return (torch.empty((0, 2), dtype=torch.int64, device=dev), torch.empty((0,), dtype=torch.int64, device=dev))
+    r = torch.cat(parts, dim=0).to(torch.int64)
+    return r[:, 0:2].contiguous(), r[:, 2].contiguous()
+
+
 def extract_patches(img: torch.Tensor, keypoints: torch.Tensor, patch_size: int = 24) -> torch.Tensor:
     """model_utils.py:19-36: img (1,H,W) normalised f32, keypoints (K,2) int (x,y) -> (K,24,24), zero padded."""
     if patch_size != 24:

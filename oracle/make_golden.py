@@ -213,6 +213,15 @@ def main():
     assert np.array_equal(lut, O.pre_bgr_image(np.arange(256, dtype=np.uint8).reshape(16, 16)).reshape(256))
     np.savez_compressed(os.path.join(outdir, "pre_bgr_lut.npz"), lut=lut.astype(np.float32))
 
+    # label_to_keypoints (model_utils.py:91-124) on label maps of its own: also cells whose id fires while loc == 64
+    g = torch.Generator().manual_seed(11)
+    for (n_, hc_, wc_, dust_) in ((1, 30, 40, 16), (3, 7, 9, 16), (2, 12, 5, 3)):
+        loc_m = torch.randint(0, 65, (n_, hc_, wc_), generator=g)
+        ids_m = torch.where(torch.rand((n_, hc_, wc_), generator=g) < 0.8, torch.tensor(dust_), torch.randint(0, 17, (n_, hc_, wc_), generator=g))
+        rk, ri = ref_mu.label_to_keypoints(loc_m, ids_m, dust_)
+        ok_, oi_ = O.label_to_keypoints(loc_m, ids_m, dust_)
+        assert torch.equal(rk.to(torch.int64), ok_.to(torch.int64)) and torch.equal(ri, oi_) and rk.shape[0] > 0
+
     for c in CASES:
         name = c["name"]
         sd_dc = W.synthetic_state_dict("detector", c["wseed"], N_IDS)

@@ -281,6 +281,32 @@ def test_decode_matches_oracle_exactly_with_ties_and_empty(dev):
     assert k.shape == (0, 2) and i.shape == (0,)
 
 
+def test_label_to_keypoints_on_label_maps(dev):
+    """label_to_keypoints (model_utils.py:91-124) as its own entry: random class-index maps incl. cells whose id fires while
+    loc == 64 (x = 8 ix, y = 8 iy + 8 by the reference's formula), an all-dust-bin map, a dust_bin that is not n_ids; and
+    pred_argmax -> label_to_keypoints == pred_to_keypoints on logits."""
+    from deepcharuco_amd.models.model_utils import label_to_keypoints, pred_argmax, pred_to_keypoints
+    g = torch.Generator().manual_seed(11)
+    for (n, hc, wc, dust) in ((1, 30, 40, 16), (3, 7, 9, 16), (2, 12, 5, 3)):
+        loc = torch.randint(0, 65, (n, hc, wc), generator=g)
+        ids = torch.where(torch.rand((n, hc, wc), generator=g) < 0.8, torch.tensor(dust), torch.randint(0, 17, (n, hc, wc), generator=g))
+        k, i = label_to_keypoints(loc.to(dev), ids.to(dev), dust)
+        ek, ei = O.label_to_keypoints(loc, ids, dust)
+        assert k.dtype == torch.int64 and i.dtype == torch.int64
+        assert torch.equal(k.cpu(), ek.to(torch.int64)) and torch.equal(i.cpu(), ei) and ek.shape[0] > 0
+    none = label_to_keypoints(torch.zeros((2, 4, 4), dtype=torch.int64, device=dev), torch.full((2, 4, 4), 16, device=dev), 16)
+    assert none[0].shape == (0, 2) and none[1].shape == (0,)
+    loc_l, ids_l = torch.randn(2, 65, 9, 11, generator=g), torch.randn(2, 17, 9, 11, generator=g)
+    la, ia = pred_argmax(loc_l.to(dev), ids_l.to(dev), 16)
+    k1, i1 = label_to_keypoints(la, ia, 16)
+    k2, i2 = pred_to_keypoints(loc_l.to(dev), ids_l.to(dev), 16)
+    assert torch.equal(k1, k2) and torch.equal(i1, i2) and k1.shape[0] > 20
+    with pytest.raises(ValueError):
+        label_to_keypoints(torch.full((1, 2, 2), 300, device=dev), torch.zeros((1, 2, 2), dtype=torch.int64, device=dev), 16)
+    with pytest.raises(ValueError):
+        label_to_keypoints(torch.zeros((1, 2, 2), dtype=torch.int64), torch.zeros((1, 2, 2), dtype=torch.int64), 16)     # CPU tensors: no CPU path
+
+
 def test_extract_patches_border_and_golden(dev, golden):
     from deepcharuco_amd.models.model_utils import extract_patches
     fx = golden.fx
@@ -403,6 +429,35 @@ def test_fused_tail_on_diverse_ids_hundreds_of_cells(dev):
             bad += 1
     _report("diverse_ids/fused_tail", dict(frames=len(frames), corners=int(hist.sum()), per_id=hist.tolist(), mismatched_frames=bad))
     assert hist.sum() > 300 and (hist > 0).sum() >= 14 and bad == 0
+
+
+def test_draw_pred_draws_both_stages_on_a_copy(dev, golden_tiny, monkeypatch):
+    """infer_image(draw_pred=True) (inference.py:47-50,63-66): the detector's key-points in red (radius 3, ids) and the refined
+    corners in yellow (radius 1), on a copy; the key-points returned are those of the plain call.  OpenCV's drawing calls are
+    recorded by a stand-in (cv2 is not installable here)."""
+    import sys
+    from test_host_logic import _RecordingCv2
+    from deepcharuco_amd.inference import infer_image
+    dc, rn = _models(golden_tiny, dev)
+    fx = golden_tiny.fx
+    rec = _RecordingCv2()
+    from deepcharuco_amd import imgproc
+    monkeypatch.setattr(imgproc, "_cv2", False)           # BGR->gray keeps using the device formula: the stand-in only draws
+    monkeypatch.setitem(sys.modules, "cv2", rec)
+    bgr = golden_tiny.bgr
+    before = bgr.copy()
+    kp, img = infer_image(bgr, 16, dc, rn, draw_pred=True, device="cuda")
+    assert np.array_equal(kp, fx["final_rn"]) and img is not bgr and np.array_equal(bgr, before)
+    circles = [c for c in rec.calls if c[0] == "circle"]
+    k = fx["kpts"].shape[0]
+    assert len(circles) == 2 * k
+    assert [c[1] for c in circles[:k]] == [tuple(int(v) for v in p) for p in fx["kpts"]] and all(c[2] == 3 and c[3] == (0, 0, 255) for c in circles[:k])
+    assert all(c[2] == 1 and c[3] == (0, 255, 255) for c in circles[k:])
+    assert [c[1] for c in circles[k:]] == [tuple(int(v) for v in np.round(p).astype(int)) for p in fx["corners_og"]]
+    assert [t[1] for t in rec.calls if t[0] == "text"] == [str(int(i)) for i in fx["ids_found"]]
+    rec.calls.clear()
+    kp2, img2 = infer_image(bgr, 16, dc, None, draw_pred=True, device="cuda")
+    assert np.array_equal(kp2, fx["final_norn"]) and len([c for c in rec.calls if c[0] == "circle"]) == k
 
 
 def test_no_corner_returns_empty_array(dev, golden_tiny):

@@ -484,3 +484,44 @@ def test_lds_bank_model_of_the_raw_tile_layouts():
     # the constants the header uses for the planar tile (csrc/dcx_conv_wino2h.h)
     src = open(os.path.join(REPO, "deepcharuco_amd", "csrc", "dcx_conv_wino2h.h")).read()
     assert "PRP = 13, PODD = 108, PCQ = 216" in src
+
+
+class _RecordingCv2:
+    """Stand-in for the three drawing calls of OpenCV (cv2 is not installable here): records what it is asked to draw."""
+    FONT_HERSHEY_COMPLEX_SMALL = 5
+
+    def __init__(self):
+        self.calls = []
+
+    def circle(self, img, center, radius, color, thickness):
+        self.calls.append(("circle", center, radius, color, thickness))
+        img[min(center[1], img.shape[0] - 1), min(center[0], img.shape[1] - 1)] = color
+
+    def getTextSize(self, text, font, scale, thickness):
+        return (8 * len(text), 10), 3
+
+    def putText(self, img, text, pos, font, scale, color, thickness):
+        self.calls.append(("text", text, pos, color))
+
+
+def test_draw_inner_corners_semantics(monkeypatch):
+    """draw_pred=True (inference.py:47-50,63-66 -> aruco_utils.draw_inner_corners:135-192): drawing happens on a COPY, corners are
+    rounded to the nearest pixel, corners beyond the right / bottom edge are skipped, ids are drawn in green only when asked."""
+    import sys
+    from deepcharuco_amd import inference as I
+    rec = _RecordingCv2()
+    monkeypatch.setitem(sys.modules, "cv2", rec)
+    img = np.zeros((20, 30, 3), np.uint8)
+    corners = np.array([[3.4, 4.6], [29.5, 19.49], [31.0, 5.0], [5.0, 21.0]])
+    out = I.draw_inner_corners(img, corners, np.array([7, 12, 1, 2]), draw_ids=True, radius=3, color=(0, 0, 255))
+    assert out is not img and not img.any() and out.any()
+    circles = [c for c in rec.calls if c[0] == "circle"]
+    assert [c[1] for c in circles] == [(3, 5), (30, 19)] and all(c[2] == 3 and c[3] == (0, 0, 255) and c[4] == 1 for c in circles)
+    texts = [c for c in rec.calls if c[0] == "text"]
+    assert [t[1] for t in texts] == ["7", "12"] and texts[0][2] == (3 - 4 - 7, 5 + 5 - 3) and all(t[3] == (0, 255, 0) for t in texts)
+    rec.calls.clear()
+    I.draw_inner_corners(img, corners[:1], np.array([7]), draw_ids=False, radius=1, color=(0, 255, 255))
+    assert rec.calls == [("circle", (3, 5), 1, (0, 255, 255), 1)]
+    monkeypatch.setitem(sys.modules, "cv2", None)
+    with pytest.raises(ImportError, match="OpenCV"):
+        I.draw_inner_corners(img, corners, np.array([7, 12, 1, 2]))
