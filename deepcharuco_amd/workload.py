@@ -58,12 +58,13 @@ def _logits_on(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: int):
 
 
 def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: int = 16, per_frame: int = 16,
-                      diverse_ids: bool = False) -> W.StateDict:
+                      diverse_ids: bool = False, kmax: int = 0) -> W.StateDict:
     """Returns a copy of ``sd_dc`` whose ``convDb.bias[n_ids]`` makes ``per_frame * B`` cells fire on ``frames_dev``
     (HIP detector logits -> host numpy; the (k-th, k+1-th) largest non-dust-bin margins bracket the shift).
 
     ``diverse_ids``: first equalise ``convDb.bias[0:n_ids]`` per class (``weights.diverse_ids_bias_shift``) so that the firing
-    cells carry all the ids of the board instead of the one or two a random-init ids head lets win everywhere."""
+    cells carry all the ids of the board instead of the one or two a random-init ids head lets win everywhere.
+    ``kmax``: the pipeline's corner capacity per frame -- cells beyond it are not counted towards the target."""
     sd = {k_: v.copy() for k_, v in sd_dc.items()}
     k = per_frame * frames_dev.shape[0]
     la, ids = _logits_on(sd, frames_dev, dev, n_ids)
@@ -72,8 +73,25 @@ def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: 
         sd["convDb.bias"][:n_ids] = (sd["convDb.bias"][:n_ids] + shift).astype(np.float32)
         la, ids = _logits_on(sd, frames_dev, dev, n_ids)      # the detector's own logits with the shifted biases (not ids + shift)
     m = ids[:, :n_ids].max(1) - ids[:, n_ids]
-    m = np.sort(np.where(la == 64, -1e30, m).ravel())[::-1]
-    delta = np.float32((m[k - 1] + m[k]) / 2)
+    mm = np.where(la == 64, -1e30, m)
+    flat = mm.ravel()
+    order = np.argsort(-flat, kind="stable")
+    if kmax > 0:
+        # the pipeline refines at most kmax corners per frame: count a frame's cells only up to kmax, so that the REFINED corners
+        # (what the FLOP count of the workload is based on) average per_frame exactly even when one frame fires more than kmax cells
+        frame_of = order // (flat.size // frames_dev.shape[0])
+        seen = np.zeros(frames_dev.shape[0], np.int64)
+        total, k_eff = 0, k
+        for j, f in enumerate(frame_of):
+            if seen[f] < kmax:
+                total += 1
+            seen[f] += 1
+            if total == k:
+                k_eff = j + 1
+                break
+        k = k_eff
+    ms = flat[order]
+    delta = np.float32((ms[k - 1] + ms[k]) / 2)
     sd["convDb.bias"][n_ids] = np.float32(sd["convDb.bias"][n_ids] + delta)
     return sd
 
