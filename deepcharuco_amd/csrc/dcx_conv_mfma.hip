@@ -128,8 +128,7 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
             const long ht = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
             const long items = (long)((n + c.group - 1) / c.group) * (cout_pad / c.cout_tile) * ht;
             // per item: 128 MFMAs of 32 cycles per unit + the transform's serial VALU + half an epilogue; stalls are hidden by the
-            // co-resident workgroup (measured, tools/unit_probe.py); the 6x20 tile's units measure ~140 cycles longer (unit probes; NOT its
-            // former LDS bank conflicts -- removing them in round 4 changed nothing: 30 of its 32 tile slots are real, its raw rows are wider)
+            // co-resident workgroup (measured, tools/unit_probe.py); the 6x20 tile's transform reads are 2-way bank-conflicted
             double item_cost = (double)units * (64 * 64.0 + (c.tw == 20 ? 700.0 : 560.0)) + 2600.0;
             if (c.acc_tiles == 4)        // 16-tile items: half the serial chain per item, but twice the weight loads and 1.56x the halo per
                                          // MFMA -- they win where a launch cannot fill the chip (bs = 1: the launch takes ONE item's chain)
