@@ -91,6 +91,7 @@ def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: 
                 break
         k = k_eff
     ms = flat[order]
+    k = max(1, min(k, flat.size - 1))
     delta = np.float32((ms[k - 1] + ms[k]) / 2)
     sd["convDb.bias"][n_ids] = np.float32(sd["convDb.bias"][n_ids] + delta)
     return sd
