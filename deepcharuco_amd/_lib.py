@@ -66,7 +66,7 @@ SIGNATURES = {
     "dcx_refiner_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "dcx_argmax2d": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dcx_pipeline_workspace_bytes": (_sz, [_vp, _vp, _i, _i, _i, _i]),
-    "dcx_infer_batch": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dcx_infer_batch": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcx_conv_layer": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "dcx_nchw_to_c4": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dcx_c4_to_nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -229,7 +229,7 @@ struct dcx_refiner {
 namespace {
 
 struct DetWs {
-    size_t buf0, buf1, loc, ids, codes, total;
+    size_t buf0, buf1, loc, ids, codes, conf, total;
     int ids_quads;
 };
 DetWs det_layout(int n_ids, int b, int h, int w) {
@@ -242,6 +242,7 @@ DetWs det_layout(int n_ids, int b, int h, int w) {
     L.loc = off;  off = align_up(off + (size_t)b * 68 * cells * 4, 256);
     L.ids = off;  off = align_up(off + (size_t)b * L.ids_quads * 4 * cells * 4, 256);
     L.codes = off; off = align_up(off + (size_t)b * cells * 4, 256);    // decode scratch: packed arg-max per cell
+    L.conf = off; off = align_up(off + (size_t)b * cells * 8, 256);     // soft-max probability of the winning (loc, ids) class per cell
     L.total = off;
     return L;
 }
@@ -348,22 +349,22 @@ extern "C" size_t dcx_detector_workspace_bytes(const dcx_detector* det, int batc
 namespace {
 // conv1a .. convPa|convDa; with_heads: also the two raw 1x1 heads into the workspace's C4 logit buffers (dcModel.forward).
 // Without them the 512-channel activation is left in buf0 for the fused tail kernel (dcx_tail.hip).
-int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch,
+int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch, int pix,
                  const float* d_images_f32, int batch, int height, int width, void* d_ws, size_t ws_bytes,
-                 bool with_heads, float* d_loc_nchw, float* d_ids_nchw, void* stream);
+                 bool with_heads, float* d_loc_nchw, float* d_ids_nchw, int32_t* zero_words, int n_zero, void* stream);
 }  // namespace
 
 extern "C" int dcx_detector_forward(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch,
                                     const float* d_images_f32, int batch, int height, int width, void* d_ws,
                                     size_t ws_bytes, float* d_loc_nchw, float* d_ids_nchw, void* stream) {
-    return detector_run(det, d_frames_u8, frame_stride, pitch, d_images_f32, batch, height, width, d_ws, ws_bytes, true,
-                        d_loc_nchw, d_ids_nchw, stream);
+    return detector_run(det, d_frames_u8, frame_stride, pitch, DCX_PIX_GRAY8, d_images_f32, batch, height, width, d_ws, ws_bytes, true,
+                        d_loc_nchw, d_ids_nchw, nullptr, 0, stream);
 }
 
 namespace {
-int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch,
+int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame_stride, int pitch, int pix,
                  const float* d_images_f32, int batch, int height, int width, void* d_ws, size_t ws_bytes,
-                 bool with_heads, float* d_loc_nchw, float* d_ids_nchw, void* stream) {
+                 bool with_heads, float* d_loc_nchw, float* d_ids_nchw, int32_t* zero_words, int n_zero, void* stream) {
     if (!det || !d_ws) return DCX_E_ARG;
     if ((d_frames_u8 == nullptr) == (d_images_f32 == nullptr)) return DCX_E_ARG;
     if (batch <= 0 || height < 8 || width < 8) return DCX_E_SHAPE;      // any size >= 8: the three poolings floor (net.py:16)
@@ -379,8 +380,8 @@ int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame
     int rc;
     // conv1a + bn1a + relu (net.py:60)
     if (d_frames_u8)
-        rc = dcx_launch_conv1_u8(d_frames_u8, frame_stride, pitch, batch, h, w, 1, det->first.w, det->first.bias,
-                                 det->first.alpha, det->first.beta, buf0, nullptr, s);
+        rc = dcx_launch_conv1_u8(d_frames_u8, frame_stride, pitch, pix, batch, h, w, 1, det->first.w, det->first.bias,
+                                 det->first.alpha, det->first.beta, buf0, nullptr, zero_words, n_zero, s);
     else
         rc = dcx_launch_conv1_f32(d_images_f32, (long)h * w, w, batch, h, w, 1, det->first.w, det->first.bias,
                                   det->first.alpha, det->first.beta, buf0, nullptr, s);
@@ -482,7 +483,7 @@ namespace {
 // n_hint: how many of the max_patches slots are expected to be live (0: unknown).  The launches are sized for the capacity
 // and skip dead patches through d_total on the device; the hint only steers the tile cost model (at bs=1 the capacity is 64
 // slots but ~16 corners fire: tiles chosen for 64 patches run a 4x longer serial chain per workgroup than needed).
-struct FrameSrc { const uint8_t* frames; long frame_stride; int pitch, height, width; };   // pipeline: patches come out of the frames
+struct FrameSrc { const uint8_t* frames; long frame_stride; int pitch, pix, height, width; };   // pipeline: patches come out of the frames
 int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* fsrc, int max_patches, int n_hint,
                 const int32_t* d_total, const int32_t* d_table, void* d_ws, size_t ws_bytes, int32_t* d_corners, float* d_xy,
                 float* d_heat, void* stream);
@@ -512,7 +513,7 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* f
     const int* lim = d_total;
     // conv1a (pad 0) 24 -> 22 (refinenet.py:56); in the pipeline fused with extract_patches (model_utils.py:19-36)
     int rc = fsrc != nullptr
-        ? dcx_launch_conv1_patches_u8(fsrc->frames, fsrc->frame_stride, fsrc->pitch, fsrc->height, fsrc->width, d_table, d_total, p, n_hint,
+        ? dcx_launch_conv1_patches_u8(fsrc->frames, fsrc->frame_stride, fsrc->pitch, fsrc->pix, fsrc->height, fsrc->width, d_table, d_total, p, n_hint,
                                       rf->first.w, rf->first.bias, rf->first.alpha, rf->first.beta, buf0, s)
         : dcx_launch_conv1_f32(d_patches, 576, 24, p, 24, 24, 0, rf->first.w, rf->first.bias, rf->first.alpha,
                                rf->first.beta, buf0, lim, s);
@@ -557,70 +558,66 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* f
 
 // ---- whole pipeline -----------------------------------------------------------------------------
 namespace {
-struct PipeWs { size_t det, table, total_i, ref, total; };
-PipeWs pipe_layout(const dcx_detector* det, const dcx_refiner* rf, int b, int h, int w, int kmax) {
+// ctrl: int32 words cleared by the detector's first kernel: [0] = pool cursor (ends as the batch's firing-cell count = RefineNet's
+// n_limit), [64 .. 64 + B) = the frames' tail tickets
+struct PipeWs { size_t det, table, ctrl, ref, total; int ctrl_words; };
+PipeWs pipe_layout(const dcx_detector* det, const dcx_refiner* rf, int b, int h, int w, int pool) {
     PipeWs L;
-    const size_t p = (size_t)b * kmax;
     size_t off = 0;
     L.det = off; off = align_up(off + det_layout(det->n_ids, b, h, w).total, 256);
-    L.table = off; off = align_up(off + p * 16, 256);
-    L.total_i = off; off = align_up(off + 256, 256);
-    L.ref = off; off = align_up(off + (rf ? ref_layout((int)p).total : 0), 256);
+    L.table = off; off = align_up(off + (size_t)pool * 16, 256);
+    L.ctrl_words = 64 + b;
+    L.ctrl = off; off = align_up(off + (size_t)L.ctrl_words * 4, 256);
+    L.ref = off; off = align_up(off + (rf ? ref_layout(pool).total : 0), 256);
     L.total = off;
     return L;
 }
 }  // namespace
 
 extern "C" size_t dcx_pipeline_workspace_bytes(const dcx_detector* det, const dcx_refiner* rf, int batch, int height,
-                                               int width, int kmax) {
-    if (!det || batch <= 0 || height <= 0 || width <= 0 || kmax <= 0) return 0;
-    return pipe_layout(det, rf, batch, height, width, kmax).total;
+                                               int width, int pool) {
+    if (!det || batch <= 0 || height <= 0 || width <= 0 || pool <= 0) return 0;
+    return pipe_layout(det, rf, batch, height, width, pool).total;
 }
 
 namespace {
 // the whole path for frames [0, batch) on ONE stream
-int infer_range(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d_frames_u8, long frame_stride, int pitch,
-                int batch, int height, int width, int dust_bin, int kmax, char* ws, size_t ws_bytes, int32_t* d_counts,
-                int32_t* d_rows, float* d_xy, hipStream_t s, bool timing) {
+int infer_range(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d_frames_u8, long frame_stride, int pitch, int pix,
+                int batch, int height, int width, int dust_bin, int pool, char* ws, size_t ws_bytes, int32_t* d_counts,
+                int32_t* d_starts, int32_t* d_rows, float* d_xy, float* d_conf, hipStream_t s, bool timing) {
     void* stream = (void*)s;
-    const PipeWs L = pipe_layout(det, rf, batch, height, width, kmax);
+    const PipeWs L = pipe_layout(det, rf, batch, height, width, pool);
     if (ws_bytes < L.total) return DCX_E_WS;
     int rc = timing ? timing_mark(0, s) : 0;
     if (rc) return rc;
-    // detector up to convPa|convDa, then ONE kernel for the 1x1 heads + per-cell arg-max + dust-bin rule (the logits never
-    // reach HBM; dcModel.forward keeps the separate heads because it has to return them), then the ordered compaction
-    rc = detector_run(det, d_frames_u8, frame_stride, pitch, nullptr, batch, height, width, ws + L.det, L.table - L.det,
-                      false, nullptr, nullptr, stream);
+    int32_t* ctrl = (int32_t*)(ws + L.ctrl);
+    // detector up to convPa|convDa (its first kernel also clears the pool cursor and the frame tickets), then ONE kernel for the
+    // 1x1 heads + per-cell arg-max + dust-bin rule + ordered compaction into the batch's corner pool (the logits never reach HBM;
+    // dcModel.forward keeps the separate heads because it has to return them)
+    rc = detector_run(det, d_frames_u8, frame_stride, pitch, pix, nullptr, batch, height, width, ws + L.det, L.table - L.det,
+                      false, nullptr, nullptr, ctrl, L.ctrl_words, stream);
     if (rc) return rc;
     if (timing && (rc = timing_mark(1, s))) return rc;
+    int32_t* table = (int32_t*)(ws + L.table);
     {
         const DetWs D = det_layout(det->n_ids, batch, height, width);
         const int hc = height / 8, wc = width / 8;
         const float* act = (const float*)(ws + L.det + D.buf0);
         int32_t* codes = (int32_t*)(ws + L.det + D.codes);
-        // total_i: [0] = live patches of the batch, [1] = ticket of the compaction kernel (cleared by the tail kernel)
-        int32_t* total = (int32_t*)(ws + L.total_i);
+        DcxPoolOut po;
+        po.tickets = ctrl + 64; po.cursor = ctrl; po.counts = d_counts; po.starts = d_starts; po.rows = d_rows;
+        po.table = rf ? table : nullptr; po.conf = d_conf; po.conf_cells = (float*)(ws + L.det + D.conf);
+        po.wc = wc; po.pool = pool;
         rc = dcx_launch_tail(act, batch, hc * wc, det->head_loc.w, det->head_loc.bias, det->head_ids.w, det->head_ids.bias,
-                             det->head_ids.cout_pad, det->n_ids + 1, dust_bin, codes, nullptr, nullptr, rf ? total + 1 : nullptr, s);
-        if (rc) return rc;
-        if (rf == nullptr) {
-            rc = dcx_launch_compact(codes, batch, hc, wc, dust_bin, kmax, d_counts, d_rows, s);
-            if (rc) return rc;
-            if (timing && (rc = timing_mark(2, s))) return rc;
-            return timing ? timing_mark(3, s) : 0;
-        }
-        // ordered compaction per frame + (last workgroup) the patch table of the batch: one launch
-        rc = dcx_launch_compact_table(codes, batch, hc, wc, dust_bin, kmax, d_counts, d_rows, (int32_t*)(ws + L.table), total,
-                                      total + 1, s);
+                             det->head_ids.cout_pad, det->n_ids + 1, dust_bin, codes, nullptr, nullptr, &po, s);
         if (rc) return rc;
     }
-    int32_t* table = (int32_t*)(ws + L.table);
-    int32_t* total = (int32_t*)(ws + L.total_i);
-    const int p = batch * kmax;
     if (timing && (rc = timing_mark(2, s))) return rc;
-    // expected live patches: a board has n_ids corners, so ~n_ids fire per frame (the capacity kmax is usually larger)
-    const FrameSrc src{d_frames_u8, frame_stride, pitch, height, width};       // RefineNet's conv1a gathers its 24x24 patches itself
-    rc = refiner_run(rf, nullptr, &src, p, batch * (kmax < det->n_ids ? kmax : det->n_ids), total, table,
+    if (rf == nullptr) return timing ? timing_mark(3, s) : 0;
+    // expected live patches: a board has n_ids corners, so ~n_ids fire per frame (the pool is usually larger)
+    const long expect = (long)batch * det->n_ids;
+    const FrameSrc src{d_frames_u8, frame_stride, pitch, pix, height, width};       // RefineNet's conv1a gathers its 24x24 patches itself
+    rc = refiner_run(rf, nullptr, &src, pool, (int)(expect < pool ? expect : pool), ctrl, table,
                      ws + L.ref, L.total - L.ref, nullptr, d_xy, nullptr, stream);
     if (rc) return rc;
     return timing ? timing_mark(3, s) : 0;
@@ -628,21 +625,23 @@ int infer_range(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d
 }  // namespace
 
 extern "C" int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d_frames_u8,
-                               long frame_stride, int pitch, int batch, int height, int width, int dust_bin, int kmax,
-                               void* d_ws, size_t ws_bytes, int32_t* d_counts, int32_t* d_rows, float* d_xy,
-                               void* stream) {
-    if (!det || !d_frames_u8 || !d_ws || !d_counts || !d_rows) return DCX_E_ARG;
+                               long frame_stride, int pitch, int pixel_format, int batch, int height, int width, int dust_bin,
+                               int pool, void* d_ws, size_t ws_bytes, int32_t* d_counts, int32_t* d_starts, int32_t* d_rows,
+                               float* d_xy, float* d_conf, void* stream) {
+    if (!det || !d_frames_u8 || !d_ws || !d_counts || !d_starts || !d_rows) return DCX_E_ARG;
     if (rf != nullptr && d_xy == nullptr) return DCX_E_ARG;
-    if (kmax <= 0 || (long)batch * kmax > (1 << 22)) return DCX_E_SHAPE;
-    if (batch <= 0 || height < 8 || width < 8) return DCX_E_SHAPE;      // any size >= 8: the three poolings floor (net.py:16)
+    if (pixel_format != DCX_PIX_GRAY8 && pixel_format != DCX_PIX_BGR8 && pixel_format != DCX_PIX_BGR8_LEGACY14) return DCX_E_ARG;
+    if (pool <= 0 || pool > (1 << 22)) return DCX_E_SHAPE;
+    if (batch <= 0 || batch > (1 << 20) || height < 8 || width < 8) return DCX_E_SHAPE;      // any size >= 8: the three poolings floor (net.py:16)
+    if (pitch < width * (pixel_format == DCX_PIX_GRAY8 ? 1 : 3)) return DCX_E_SHAPE;
     if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)d_ws;
     // (A fork/join two-stream variant -- two half-batches of one call on two streams -- was measured and dropped: -1 % at
     //  bs=32.  What does gain ~7 % is overlapping CONSECUTIVE batches on two streams, which is the caller's business:
     //  tools/two_stream_probe.py.)
-    return infer_range(det, rf, d_frames_u8, frame_stride, pitch, batch, height, width, dust_bin, kmax, ws, ws_bytes,
-                       d_counts, d_rows, d_xy, s, true);
+    return infer_range(det, rf, d_frames_u8, frame_stride, pitch, pixel_format, batch, height, width, dust_bin, pool, ws, ws_bytes,
+                       d_counts, d_starts, d_rows, d_xy, d_conf, s, true);
 }
 
 extern "C" int dcx_set_timing(int enabled) { g_timing = enabled != 0; return 0; }

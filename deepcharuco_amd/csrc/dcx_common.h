@@ -74,9 +74,12 @@ int dcx_conv_heat_tiles(int ho, int wo, int ups);
 // ---------------------------------------------------------------------------------------
 // everything else (dcx_misc.hip)
 
-int dcx_launch_conv1_u8(const uint8_t* frames, long frame_stride, int pitch, int n, int h, int w, int pad,
+// pix: DCX_PIX_GRAY8 / DCX_PIX_BGR8 / DCX_PIX_BGR8_LEGACY14 (BGR -> gray in the load, the integer formula of dcx_bgr2gray);
+// frame_stride / pitch in BYTES.  zero_words / n_zero (nullable): int32 words workgroup (0, 0) clears -- the pipeline's pool
+// cursor and frame tickets, which the tail kernel nine launches later expects to be 0.
+int dcx_launch_conv1_u8(const uint8_t* frames, long frame_stride, int pitch, int pix, int n, int h, int w, int pad,
                         const float* w9x64, const float* bias, const float* alpha, const float* beta,
-                        float* out_c4, const int* n_limit, hipStream_t s);
+                        float* out_c4, const int* n_limit, int32_t* zero_words, int n_zero, hipStream_t s);
 int dcx_launch_conv1_f32(const float* images, long image_stride, int pitch, int n, int h, int w, int pad,
                          const float* w9x64, const float* bias, const float* alpha, const float* beta,
                          float* out_c4, const int* n_limit, hipStream_t s);
@@ -89,21 +92,30 @@ struct DcxLogitView {
 int dcx_launch_decode(DcxLogitView loc, DcxLogitView ids, int batch, int n_loc, int n_ids1, int hc, int wc,
                       int dust_bin, int kmax, int32_t* counts, int32_t* rows,
                       int32_t* loc_argmax, int32_t* ids_argmax, int32_t* codes_scratch, hipStream_t s);
-// fused detector tail (dcx_tail.hip): 1x1 heads + per-cell arg-max + dust-bin rule -> packed codes (loc | id << 8)
+// The batch's corner pool, filled by the fused detector tail (dcx_tail.hip): frame b's firing cells occupy the pool slots
+// [starts[b], starts[b] + counts[b]) in raster order; slots >= pool are dropped (the caller sees sum(counts) > pool).
+struct DcxPoolOut {
+    int32_t* tickets;      // [B]  per-frame arrival counters of the tail's work items, 0 at entry
+    int32_t* cursor;       // [1]  0 at entry; ends as the number of firing cells of the batch (may exceed pool) = RefineNet's n_limit
+    int32_t* counts;       // [B]  firing cells of frame b (never truncated)
+    int32_t* starts;       // [B]  first pool slot of frame b
+    int32_t* rows;         // [pool][4] = (x, y, id, cell)
+    int32_t* table;        // nullable [pool][4] = (frame, x, y, slot): RefineNet's patch table
+    float* conf;           // nullable [pool][2] = soft-max probability of the winning (loc, ids) class
+    float* conf_cells;     // [B][cells][2] scratch, needed when conf is given
+    int wc, pool;
+};
+// fused detector tail (dcx_tail.hip): 1x1 heads + per-cell arg-max + dust-bin rule -> packed codes (loc | id << 8) and, with
+// `po`, the ordered compaction of every frame into the batch's corner pool (done by the frame's last work item)
 int dcx_launch_tail(const float* act_c4_512, int batch, int cells, const float* w_loc, const float* b_loc,
                     const float* w_ids, const float* b_ids, int ids_cout_pad, int n_ids1, int dust_bin,
-                    int32_t* codes, int32_t* loc_argmax, int32_t* ids_argmax, int32_t* zero_word, hipStream_t s);
-                    // zero_word (nullable): an int32 the kernel clears -- the ticket of the dcx_launch_compact_table that follows
-// ordered compaction of packed codes into per-frame rows (dcx_misc.hip)
+                    int32_t* codes, int32_t* loc_argmax, int32_t* ids_argmax, const DcxPoolOut* po, hipStream_t s);
+// ordered compaction of packed codes into per-frame rows [B][kmax][4] (dcx_misc.hip; stand-alone decode entry points)
 int dcx_launch_compact(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
                        int32_t* rows, hipStream_t s);
-// the same compaction + (last workgroup to finish) the patch table of the whole batch: exclusive scan of min(counts, kmax),
-// table[slot] = (frame, x, y, frame * kmax + k), *total = live patches.  *ticket must be 0 at entry (it is left 0).
-int dcx_launch_compact_table(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
-                             int32_t* rows, int32_t* table, int32_t* total, int32_t* ticket, hipStream_t s);
 // RefineNet conv1a (pad 0, 24x24 -> 22x22) reading its patches straight out of the u8 frames through the patch table
 // (extract_patches + pre_bgr_image + conv1a in one kernel: the patch tensor is never materialised)
-int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int h, int w, const int32_t* table,
+int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int pix, int h, int w, const int32_t* table,
                                 const int* total, int max_patches, int n_hint, const float* w9x64, const float* bias,
                                 const float* alpha, const float* beta, float* out_c4, hipStream_t s);
 int dcx_launch_refine_finalize(const float* part_val, const int* part_idx, int tiles, int wo,

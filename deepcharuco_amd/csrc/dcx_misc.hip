@@ -11,21 +11,51 @@ __device__ __forceinline__ float dcx_norm_u8(uint8_t g) { return ((float)g - 128
 __device__ __forceinline__ float dcx_load_px(const uint8_t* p) { return dcx_norm_u8(*p); }
 __device__ __forceinline__ float dcx_load_px(const float* p) { return *p; }
 
+// Pixel formats of the u8 frames (DCX_PIX_*): gray, or interleaved BGR converted in the load with the integer formula of
+// cv2.cvtColor(img, COLOR_BGR2GRAY) (dcx_bgr2gray_kernel below: 15-bit OpenCV 4.x constants; legacy 14-bit ones) -- the gray
+// frame of inference.py:40 is never materialised.  BPP = bytes per pixel.
+template <int PIX> struct DcxPix;
+template <> struct DcxPix<DCX_PIX_GRAY8> {
+    static constexpr int BPP = 1;
+    static __device__ __forceinline__ float load(const uint8_t* p) { return dcx_norm_u8(*p); }
+};
+template <> struct DcxPix<DCX_PIX_BGR8> {
+    static constexpr int BPP = 3;
+    static __device__ __forceinline__ float load(const uint8_t* p) {
+        const unsigned bb = p[0], gg = p[1], rr = p[2];
+        return dcx_norm_u8((uint8_t)((bb * 3735u + gg * 19235u + rr * 9798u + (1u << 14)) >> 15));
+    }
+};
+template <> struct DcxPix<DCX_PIX_BGR8_LEGACY14> {
+    static constexpr int BPP = 3;
+    static __device__ __forceinline__ float load(const uint8_t* p) {
+        const unsigned bb = p[0], gg = p[1], rr = p[2];
+        return dcx_norm_u8((uint8_t)((bb * 1868u + gg * 9617u + rr * 4899u + (1u << 13)) >> 14));
+    }
+};
+struct DcxPixF32 {
+    static constexpr int BPP = 4;
+    static __device__ __forceinline__ float load(const uint8_t* p) { return *reinterpret_cast<const float*>(p); }
+};
+
 // ---------------------------------------------------------------------------------------
 // conv1a (+bn1a+relu), Cin = 1 -> 64: net.py:23-24,60 (pad 1) and refinenet.py:21-22,56 (pad 0).
 // One thread = one output pixel, all 64 output channels; acc = fmaf(w[tap], x[tap], acc) for
 // tap = 0..8 (dy-major), then +bias, BN affine, ReLU.  Write-bound: 256 B per pixel, C4 layout,
 // 16-B stores contiguous across lanes.
-template <typename TIn>
-__global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ in, long image_stride, int pitch,
+template <typename PX>
+__global__ __launch_bounds__(256) void dcx_conv1_kernel(const uint8_t* __restrict__ in, long image_stride, int pitch,
                                                           int h, int w, int pad,
                                                           const float* __restrict__ w9x64,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ alpha,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ out, int ho, int wo,
-                                                          const int* __restrict__ n_limit, int n_images) {
+                                                          const int* __restrict__ n_limit, int n_images,
+                                                          int32_t* __restrict__ zero_words, int n_zero) {
     __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
+    if (zero_words != nullptr && blockIdx.x == 0 && blockIdx.y == 0)      // image_stride / pitch are in BYTES
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0;
     int n_end = n_images;
     if (n_limit != nullptr) n_end = min(n_end, *n_limit);
     if ((int)blockIdx.y >= n_end) return;
@@ -40,7 +70,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ 
     if (p >= ho * wo) return;
     const int oy = p / wo, ox = p - oy * wo;
     for (int n = blockIdx.y; n < n_end; n += gridDim.y) {     // gridDim.y is capped at 65535 images
-    const TIn* img = in + (size_t)n * image_stride;
+    const uint8_t* img = in + (size_t)n * image_stride;
     float x[9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -49,7 +79,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ 
             const int iy = oy - pad + dy, ix = ox - pad + dx;
             const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
             const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
-            const float v = dcx_load_px(img + (size_t)cy * pitch + cx);
+            const float v = PX::load(img + (size_t)cy * pitch + (size_t)cx * PX::BPP);
             x[dy * 3 + dx] = inb ? v : 0.0f;   // zero padding of the NORMALISED image
         }
     float4* out4 = reinterpret_cast<float4*>(out);
@@ -80,6 +110,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const TIn* __restrict__ 
 // (y - 12 + oy + dy, x - 12 + ox + dx) of frame table[p].x around key-point (x, y) = table[p].(y, z), zero outside the image
 // (model_utils.py:19-36 pads the NORMALISED image with 0) -- the values dcx_gather_kernel would have written, the arithmetic of
 // dcx_conv1_kernel (taps 0..8 dy-major, + bias, BN affine, ReLU): bit-identical to gather + conv1a.
+template <typename PX>
 __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* __restrict__ frames, long frame_stride, int pitch,
                                                                   int h, int w, const int32_t* __restrict__ table,
                                                                   const int* __restrict__ total, int max_patches,
@@ -113,7 +144,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
             const int iy = t.z - 12 + i, ix = t.y - 12 + j;
             const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
             const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
-            const float v = dcx_norm_u8(img[(size_t)cy * pitch + cx]);
+            const float v = PX::load(img + (size_t)cy * pitch + (size_t)cx * PX::BPP);
             sp[e] = inb ? v : 0.0f;
         }
         __syncthreads();
@@ -147,43 +178,59 @@ __global__ __launch_bounds__(256) void dcx_conv1_patches_kernel(const uint8_t* _
     }
 }
 
-int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int h, int w, const int32_t* table,
+int dcx_launch_conv1_patches_u8(const uint8_t* frames, long frame_stride, int pitch, int pix, int h, int w, const int32_t* table,
                                 const int* total, int max_patches, int n_hint, const float* w9x64, const float* bias,
                                 const float* alpha, const float* beta, float* out_c4, hipStream_t s) {
     if (!frames || !table || !total || !w9x64 || !bias || !alpha || !beta || !out_c4) return DCX_E_ARG;
     if (max_patches <= 0 || h <= 0 || w <= 0) return DCX_E_SHAPE;
+    if (pix != DCX_PIX_GRAY8 && pix != DCX_PIX_BGR8 && pix != DCX_PIX_BGR8_LEGACY14) return DCX_E_ARG;
     // The grid covers the EXPECTED number of live patches (n_hint; the kernel strides over the rest): workgroups that only find
     // out that their slot is dead still cost a dispatch each, and at ~3 ns per workgroup 8,192 of them were the whole 24 us
     int gy = n_hint > 0 && n_hint < max_patches ? n_hint : max_patches;
     if (gy > 65535) gy = 65535;
     dim3 grid(4, (unsigned)gy);
-    hipLaunchKernelGGL(dcx_conv1_patches_kernel, grid, dim3(256), 0, s, frames, frame_stride, pitch, h, w, table, total,
-                       max_patches, w9x64, bias, alpha, beta, out_c4);
+#define DCX_P1(PX) hipLaunchKernelGGL((dcx_conv1_patches_kernel<PX>), grid, dim3(256), 0, s, frames, frame_stride, pitch, h, w, table, \
+                                     total, max_patches, w9x64, bias, alpha, beta, out_c4)
+    if (pix == DCX_PIX_GRAY8) DCX_P1(DcxPix<DCX_PIX_GRAY8>);
+    else if (pix == DCX_PIX_BGR8) DCX_P1(DcxPix<DCX_PIX_BGR8>);
+    else DCX_P1(DcxPix<DCX_PIX_BGR8_LEGACY14>);
+#undef DCX_P1
     return (int)hipGetLastError();
 }
 
-template <typename TIn>
-static int launch_conv1(const TIn* in, long image_stride, int pitch, int n, int h, int w, int pad,
+template <typename PX>
+static int launch_conv1(const uint8_t* in, long image_stride, int pitch, int n, int h, int w, int pad,
                         const float* w9x64, const float* bias, const float* alpha, const float* beta,
-                        float* out, const int* n_limit, hipStream_t s) {
+                        float* out, const int* n_limit, int32_t* zero_words, int n_zero, hipStream_t s) {
     if (!in || !w9x64 || !bias || !alpha || !beta || !out) return DCX_E_ARG;
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
     if (ho <= 0 || wo <= 0 || n <= 0) return DCX_E_SHAPE;
     dim3 grid((unsigned)((ho * wo + 255) / 256), (unsigned)(n < 65535 ? n : 65535));
-    hipLaunchKernelGGL((dcx_conv1_kernel<TIn>), grid, dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
-                       w9x64, bias, alpha, beta, out, ho, wo, n_limit, n);
+    hipLaunchKernelGGL((dcx_conv1_kernel<PX>), grid, dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
+                       w9x64, bias, alpha, beta, out, ho, wo, n_limit, n, zero_words, n_zero);
     return (int)hipGetLastError();
 }
 
-int dcx_launch_conv1_u8(const uint8_t* frames, long frame_stride, int pitch, int n, int h, int w, int pad,
+int dcx_launch_conv1_u8(const uint8_t* frames, long frame_stride, int pitch, int pix, int n, int h, int w, int pad,
                         const float* w9x64, const float* bias, const float* alpha, const float* beta,
-                        float* out_c4, const int* n_limit, hipStream_t s) {
-    return launch_conv1<uint8_t>(frames, frame_stride, pitch, n, h, w, pad, w9x64, bias, alpha, beta, out_c4, n_limit, s);
+                        float* out_c4, const int* n_limit, int32_t* zero_words, int n_zero, hipStream_t s) {
+    switch (pix) {
+        case DCX_PIX_GRAY8:
+            return launch_conv1<DcxPix<DCX_PIX_GRAY8>>(frames, frame_stride, pitch, n, h, w, pad, w9x64, bias, alpha, beta, out_c4, n_limit, zero_words, n_zero, s);
+        case DCX_PIX_BGR8:
+            return launch_conv1<DcxPix<DCX_PIX_BGR8>>(frames, frame_stride, pitch, n, h, w, pad, w9x64, bias, alpha, beta, out_c4, n_limit, zero_words, n_zero, s);
+        case DCX_PIX_BGR8_LEGACY14:
+            return launch_conv1<DcxPix<DCX_PIX_BGR8_LEGACY14>>(frames, frame_stride, pitch, n, h, w, pad, w9x64, bias, alpha, beta, out_c4, n_limit, zero_words, n_zero, s);
+        default:
+            return DCX_E_ARG;
+    }
 }
 int dcx_launch_conv1_f32(const float* images, long image_stride, int pitch, int n, int h, int w, int pad,
                          const float* w9x64, const float* bias, const float* alpha, const float* beta,
                          float* out_c4, const int* n_limit, hipStream_t s) {
-    return launch_conv1<float>(images, image_stride, pitch, n, h, w, pad, w9x64, bias, alpha, beta, out_c4, n_limit, s);
+    // element strides -> bytes
+    return launch_conv1<DcxPixF32>(reinterpret_cast<const uint8_t*>(images), image_stride * 4, pitch * 4, n, h, w, pad, w9x64, bias, alpha,
+                                   beta, out_c4, n_limit, nullptr, 0, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -459,56 +506,6 @@ __global__ __launch_bounds__(256) void dcx_patch_table_kernel(const int32_t* __r
     __shared__ int wave_tot[4];
     __shared__ int carry;
     dcx_patch_table_body(counts, rows, batch, kmax, table, total, s_cnt, s_start, wave_tot, &carry);
-}
-
-// Pipeline path: per-frame ordered compaction (one workgroup per frame) AND, in the workgroup that finishes last, the patch
-// table of the whole batch -- two launches in one ("last block" pattern: every thread publishes its rows with a device-scope
-// fence, one thread takes a ticket; the workgroup that draws the last ticket sees all counts / rows after its own fence).
-__global__ __launch_bounds__(256) void dcx_compact_table_kernel(const int32_t* __restrict__ codes, int hc, int wc, int dust_bin,
-                                                                  int kmax, int32_t* __restrict__ counts, int32_t* __restrict__ rows,
-                                                                  int batch, int32_t* __restrict__ table, int32_t* __restrict__ total,
-                                                                  int32_t* __restrict__ ticket) {
-    __shared__ int wave_cnt[4];
-    __shared__ int base_s;
-    __shared__ int s_last;
-    __shared__ int s_cnt[256], s_start[256];
-    __shared__ int wave_tot[4];
-    __shared__ int carry;
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int cells = hc * wc;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < cells; c0 += 256) {
-        const int cell = c0 + tid;
-        bool fire = false;
-        int la = 0, ia = 0;
-        if (cell < cells) {
-            const int code = codes[(size_t)b * cells + cell];
-            la = code & 255; ia = code >> 8;
-            fire = ia != dust_bin;
-        }
-        dcx_compact_chunk(fire, la, ia, cell, wc, kmax, b, wave_cnt, &base_s, rows);
-    }
-    if (tid == 0) counts[b] = base_s;
-    __threadfence();                     // this thread's rows (and counts[b]) are visible device-wide ...
-    __syncthreads();                     // ... for every thread of the workgroup, before the ticket is drawn
-    if (tid == 0) s_last = atomicAdd(ticket, 1) == batch - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                     // acquire: the other workgroups' counts / rows
-    dcx_patch_table_body(counts, rows, batch, kmax, table, total, s_cnt, s_start, wave_tot, &carry);
-    if (tid == 0) *ticket = 0;           // leave the ticket ready for the next launch
-}
-
-int dcx_launch_compact_table(const int32_t* codes, int batch, int hc, int wc, int dust_bin, int kmax, int32_t* counts,
-                             int32_t* rows, int32_t* table, int32_t* total, int32_t* ticket, hipStream_t s) {
-    if (!codes || !counts || !rows || !table || !total || !ticket) return DCX_E_ARG;
-    if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0) return DCX_E_SHAPE;
-    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
-    hipLaunchKernelGGL(dcx_compact_table_kernel, dim3((unsigned)batch), dim3(256), 0, s, codes, hc, wc, dust_bin, kmax, counts,
-                       rows, batch, table, total, ticket);
-    return (int)hipGetLastError();
 }
 
 extern "C" int dcx_build_patch_table(const int32_t* d_counts, const int32_t* d_rows, int batch, int kmax,

@@ -16,7 +16,19 @@
 // come straight from L2 (weights 130 KB, shared by every item; activations are read once per wave) with a software
 // prefetch of PF k-steps.  Epilogue: bias, in-lane arg-max over the lane's 16 couts (ascending, strict '>': first
 // maximum wins as in torch.argmax), lane-half and cross-wave combination through LDS, dust-bin rule, one int per cell.
+//
+// Round 5: the ordered compaction is part of this kernel.  Every work item draws a ticket from its FRAME's counter after its
+// codes are visible device-wide; the workgroup that draws a frame's last ticket compacts that frame's firing cells in raster
+// order (torch.nonzero's order, model_utils.py:112) into the BATCH's corner pool: one atomicAdd on the pool cursor reserves
+// `count` consecutive slots, so there is no per-frame capacity -- a frame may fire any number of cells as long as the batch
+// fits the pool (the reference refines EVERY firing cell, inference.py:51-57).  rows[p] = (x, y, id, cell), table[p] =
+// (frame, x, y, p) for RefineNet's patch gather; counts[b] / starts[b] say where frame b's corners are.  The placement of the
+// frames in the pool depends on which frame finishes first (the host unpacks by starts[]); a frame's own rows never do.
+// Optional (CONF): the soft-max probability of the winning loc / ids class of every cell (log-sum-exp over the 65 / n_ids+1
+// logits while they are in the accumulators), delivered per corner -- the "confidences" model_utils.py:81-84 mentions.
 #include "dcx_common.h"
+
+#include <string.h>
 
 typedef float dcx_t_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -24,17 +36,93 @@ namespace {
 
 constexpr int kTailPF = 2;   // prefetch distance in k-steps (measured at bs=32 with 32-cell items: 1 -> 30.8 us, 2 -> 29.4, 3 -> 30.7, 4 -> 31.9, 8 -> 37.1)
 
-template <int NT, int IDS_TILES>
+// Ordered compaction of ONE frame's packed codes into the batch's corner pool; all 256 threads of the workgroup call it.
+// Super-chunks of 2,048 cells: eight coalesced loads per thread in flight at once, wave ballots, per-(chunk, wave) counts through
+// LDS -- one L2 round trip and two barriers for a 320x240 frame (1,200 cells).
+__device__ __forceinline__ void dcx_tail_compact_frame(const int32_t* codes, int cells, int dust_bin, int b, const DcxPoolOut& po,
+                                                       int* s_cnt /*[32]*/, int* s_bcast) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nsuper = (cells + 2047) / 2048;
+    const int32_t* fc = codes + (size_t)b * cells;
+    const int idle = dust_bin << 8;                  // a code that does not fire
+    int total = 0;
+    if (nsuper > 1) {                                // big frames: the frame's count first (the pool slots are reserved before any row is written)
+        int c = 0;
+        for (int i = tid; i < cells; i += 256) c += ((fc[i] >> 8) != dust_bin) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+        if (lane == 0) s_cnt[wave] = c;
+        __syncthreads();
+        total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    int run = 0, start = 0;
+    for (int sc = 0; sc < nsuper; ++sc) {
+        int code[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int cell = sc * 2048 + c * 256 + tid;
+            code[c] = cell < cells ? fc[cell] : idle;
+        }
+        unsigned long long m[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            m[c] = __ballot((code[c] >> 8) != dust_bin);
+            if (lane == 0) s_cnt[c * 4 + wave] = __popcll(m[c]);
+        }
+        __syncthreads();
+        int base[8], acc = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int w0 = s_cnt[c * 4], w1 = s_cnt[c * 4 + 1], w2 = s_cnt[c * 4 + 2], w3 = s_cnt[c * 4 + 3];
+            base[c] = acc + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+            acc += w0 + w1 + w2 + w3;
+        }
+        if (sc == 0) {
+            if (nsuper == 1) total = acc;
+            if (tid == 0) {
+                const int st = atomicAdd(po.cursor, total);       // reserves [st, st + total) of the pool for this frame
+                po.counts[b] = total;
+                po.starts[b] = st;
+                *s_bcast = st;
+            }
+            __syncthreads();
+            start = *s_bcast;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if ((code[c] >> 8) != dust_bin) {
+                const int pos = start + run + base[c] + __popcll(m[c] & ((1ull << lane) - 1ull));
+                if (pos < po.pool) {
+                    const int cell = sc * 2048 + c * 256 + tid;
+                    const int la = code[c] & 255, ia = code[c] >> 8;
+                    const int cy = cell / po.wc, cx = cell - cy * po.wc;
+                    const int x = 8 * cx + (la & 7);              // xs = 8*ix + loc % 8    (model_utils.py:121)
+                    const int y = 8 * cy + (la >> 3);             // ys = 8*iy + loc // 8   (model_utils.py:122)
+                    reinterpret_cast<int4*>(po.rows)[pos] = make_int4(x, y, ia, cell);
+                    if (po.table) reinterpret_cast<int4*>(po.table)[pos] = make_int4(b, x, y, pos);
+                    if (po.conf) reinterpret_cast<float2*>(po.conf)[pos] = reinterpret_cast<const float2*>(po.conf_cells)[(size_t)b * cells + cell];
+                }
+            }
+        }
+        run += acc;
+        __syncthreads();                             // s_cnt is rewritten by the next super-chunk
+    }
+}
+
+template <int NT, int IDS_TILES, bool CONF>
 __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict__ act, int act_cq_total, int cells,
                                                         const float4* __restrict__ w_loc, const float* __restrict__ b_loc,
                                                         const float4* __restrict__ w_ids, const float* __restrict__ b_ids,
                                                         int ids_cout_pad, int n_ids1, int tiles_per_frame, int dust_bin,
-                                                        int32_t* __restrict__ codes, int32_t* __restrict__ loc_argmax,
-                                                        int32_t* __restrict__ ids_argmax, int32_t* __restrict__ zero_word) {
+                                                        int32_t* codes, int32_t* __restrict__ loc_argmax,
+                                                        int32_t* __restrict__ ids_argmax, DcxPoolOut po) {
     constexpr int NPIX = 32 * NT;
-    if (zero_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;     // ticket of the compaction kernel that follows
     __shared__ float red_v[4 + 1][NPIX];     // [job: loc tile 0..2, ids tile 0..1][pixel]
     __shared__ int red_i[4 + 1][NPIX];
+    __shared__ float red_s[CONF ? 4 + 1 : 1][NPIX];   // CONF: sum of exp(logit - red_v) over the job's valid couts
+    __shared__ int s_cnt[32];
+    __shared__ int s_bcast, s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int item = blockIdx.x;
@@ -99,21 +187,36 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
         for (int nt = 0; nt < NT; ++nt) {
             float best = -INFINITY;
             int besti = 0x7fffffff;
+            float lv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + 8 * (r >> 2) + 4 * half + (r & 3);
+                lv[r] = -INFINITY;
                 if (co < n_valid) {
                     const float v = acc[nt][r] + bias[co];
+                    lv[r] = v;
                     if (v > best || besti == 0x7fffffff) { best = v; besti = co; }
                 }
             }
+            float ssum = 0.f;
+            if (CONF && besti != 0x7fffffff) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ssum += lv[r] == -INFINITY ? 0.f : expf(lv[r] - best);      // ascending cout order
+            }
             const float ov = __shfl_xor(best, 32);
             const int oi = __shfl_xor(besti, 32);
+            const float os = CONF ? __shfl_xor(ssum, 32) : 0.f;
+            const float mine = best;
             if (oi != 0x7fffffff && (besti == 0x7fffffff || ov > best || (ov == best && oi < besti))) { best = ov; besti = oi; }
             if (half == 0) {
                 const int slot = is_ids ? 3 + job : wave;
                 red_v[slot][nt * 32 + l31] = best;
                 red_i[slot][nt * 32 + l31] = besti;
+                if (CONF) {      // both halves' sums re-based on the common maximum (lane half 0's term first)
+                    const float a = ssum == 0.f ? 0.f : ssum * expf(mine - best);
+                    const float c = os == 0.f ? 0.f : os * expf(ov - best);
+                    red_s[slot][nt * 32 + l31] = a + c;
+                }
             }
         }
     }
@@ -134,24 +237,54 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
                 const int ti = red_i[4][tid];
                 if (ti != 0x7fffffff && red_v[4][tid] > iv) { iv = red_v[4][tid]; ia = ti; }
             }
-            if (la == 64) ia = dust_bin;         // where(loc_argmax == 64, dust_bin, ids_argmax)  model_utils.py:76
             const size_t o = (size_t)b * cells + cell;
+            if (CONF) {
+                // softmax(logits)[arg-max] = 1 / sum_c exp(logit_c - max): the tiles' partial sums re-based on the overall maximum
+                float sl = 0.f, si = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (red_i[t][tid] != 0x7fffffff) sl += red_s[t][tid] * expf(red_v[t][tid] - lv);
+                si = red_s[3][tid] * expf(red_v[3][tid] - iv);
+                if (IDS_TILES > 1 && red_i[4][tid] != 0x7fffffff) si += red_s[4][tid] * expf(red_v[4][tid] - iv);
+                reinterpret_cast<float2*>(po.conf_cells)[o] = make_float2(1.0f / sl, 1.0f / si);
+            }
+            if (la == 64) ia = dust_bin;         // where(loc_argmax == 64, dust_bin, ids_argmax)  model_utils.py:76
             codes[o] = la | (ia << 8);
             if (loc_argmax) loc_argmax[o] = la;
             if (ids_argmax) ids_argmax[o] = ia;
         }
     }
+    if (po.tickets == nullptr) return;
+    // ---- the frame's last work item compacts the frame ("last block": every thread publishes its codes with a device-scope
+    //      fence, one thread draws the ticket; the workgroup that draws the frame's last one sees all of them after its own fence)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&po.tickets[b], 1) == tiles_per_frame - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    dcx_tail_compact_frame(codes, cells, dust_bin, b, po, s_cnt, &s_bcast);
 }
 
 }  // namespace
 
 // act: C4 [B][act_cq_total = 128][cells][4] (convPa|convDa output); w_*: packed [cin/4 = 64][cout_pad][4]; codes [B][cells].
+// po (nullable): fused ordered compaction into the batch's corner pool; po->tickets[0..batch) and *po->cursor must be 0 at entry.
 int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, const float* b_loc, const float* w_ids,
                     const float* b_ids, int ids_cout_pad, int n_ids1, int dust_bin, int32_t* codes, int32_t* loc_argmax,
-                    int32_t* ids_argmax, int32_t* zero_word, hipStream_t s) {
+                    int32_t* ids_argmax, const DcxPoolOut* po_in, hipStream_t s) {
     if (!act || !w_loc || !b_loc || !w_ids || !b_ids || !codes) return DCX_E_ARG;
     if (batch <= 0 || cells <= 0 || n_ids1 < 2 || n_ids1 > 64 || ids_cout_pad < n_ids1) return DCX_E_SHAPE;
     if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
+    DcxPoolOut po;
+    memset(&po, 0, sizeof(po));
+    if (po_in != nullptr) {
+        po = *po_in;
+        if (!po.tickets || !po.cursor || !po.counts || !po.starts || !po.rows) return DCX_E_ARG;
+        if (po.conf != nullptr && po.conf_cells == nullptr) return DCX_E_ARG;
+        if (po.wc <= 0 || cells % po.wc != 0 || po.pool <= 0) return DCX_E_SHAPE;
+    }
+    const bool conf = po.conf != nullptr;
     const bool two = n_ids1 > 32;
     // 32-cell work items: the kernel is latency-bound (operands straight from L2 / HBM into registers), so more, shorter
     // workgroups per CU win at every size (64-cell items: 41 vs 32 us at bs=32, 139 vs 119 at bs=128, 469 vs 446 at bs=128 640x480)
@@ -162,10 +295,11 @@ int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, 
     const float4* a4 = reinterpret_cast<const float4*>(act);
     const float4* wl = reinterpret_cast<const float4*>(w_loc);
     const float4* wi = reinterpret_cast<const float4*>(w_ids);
-#define DCX_TAIL_LAUNCH(NT, IT)                                                                                          \
-    hipLaunchKernelGGL((dcx_tail_kernel<NT, IT>), dim3((unsigned)items), dim3(256), 0, s, a4, 128, cells, wl, b_loc, wi, b_ids, \
-                       ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax, zero_word)
-    if (two) DCX_TAIL_LAUNCH(1, 2); else DCX_TAIL_LAUNCH(1, 1);
+#define DCX_TAIL_LAUNCH(NT, IT, CF)                                                                                      \
+    hipLaunchKernelGGL((dcx_tail_kernel<NT, IT, CF>), dim3((unsigned)items), dim3(256), 0, s, a4, 128, cells, wl, b_loc, wi, b_ids, \
+                       ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax, po)
+    if (two) { if (conf) DCX_TAIL_LAUNCH(1, 2, true); else DCX_TAIL_LAUNCH(1, 2, false); }
+    else     { if (conf) DCX_TAIL_LAUNCH(1, 1, true); else DCX_TAIL_LAUNCH(1, 1, false); }
 #undef DCX_TAIL_LAUNCH
     return (int)hipGetLastError();
 }

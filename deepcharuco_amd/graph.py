@@ -6,17 +6,20 @@ is a large part of a 0.5-0.7 ms call on MI355X.  ``GraphedPipeline`` captures th
 H2D of the frame from pinned memory, BGR->gray on the device (``dcx_bgr2gray``), the sync-free pipeline
 (``dcx_infer_batch``), D2H of the packed corner list -- into ONE hipGraph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm)
 and replays it per call: one launch from the host instead of ~30.  Results are those of ``infer_batch`` (same kernels,
-same order); a frame that fires more than ``kmax`` cells falls back to the eager path, which re-runs with a larger
-capacity.  A pipeline owns its pinned / device buffers and its stream; capture and replay are serialised process-wide by one
-lock (``_graph_lock``): concurrent ``infer_image`` callers never share staging buffers mid-flight, and no hipGraph is captured
-while another thread replays one (capturing and replaying from several threads at once hung the HIP runtime in testing) --
-callers that want concurrency across threads use ``infer_batch_device`` on their own streams.  The graph freezes the kernel
+same order); a call whose frames fire more cells than the captured corner pool holds falls back to the eager path, which
+re-runs with a pool of the right size.  BGR frames are converted inside the first layer's load (``DCX_PIX_BGR8``), so the graph
+holds no separate colour-conversion node.  A pipeline owns its pinned / device buffers and its stream.  Locking is PER DEVICE:
+replays on one GPU are serialised by that GPU's lock (concurrent ``infer_image`` callers never share staging buffers
+mid-flight), replays on different GPUs of one process run concurrently; a CAPTURE (and the destruction of a graph) takes the
+locks of all devices, because capturing while another thread replays hung the HIP runtime in testing -- callers that want
+concurrency on one GPU across threads use ``infer_batch_device`` on their own streams.  The graph freezes the kernel
 choice made at capture time, so the cache key also carries the library's process-global mode (``dcx_get_deterministic``) and
 graphs are bypassed while per-stage timing / per-launch profiling is on (their hipEvents would be frozen into or out of it).
 """
 from __future__ import annotations
 
 import threading
+import time
 import weakref
 from typing import List, Optional
 
@@ -24,8 +27,62 @@ import numpy as np
 import torch
 
 from . import _lib
-from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, unpack_results
-from .sharding import packed_len
+from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, packed_len, unpack_results
+
+
+class _DeviceLocks:
+    """One re-entrant lock per GPU.  ``device(i)``: the lock a replay on GPU i holds.  ``all()``: context manager that takes every
+    device's lock in ascending order (capture, graph destruction, cache surgery) -- a single total order, so a thread holding
+    one device's lock and another one taking all of them cannot deadlock (a replay never waits for a second lock)."""
+
+    def __init__(self):
+        self._locks = {}
+        self._guard = threading.Lock()
+        self._all = threading.RLock()           # serialises the all-device holders among themselves (also covers devices not seen yet)
+
+    def device(self, index: int) -> "threading.RLock":
+        with self._guard:
+            lk = self._locks.get(index)
+            if lk is None:
+                lk = self._locks[index] = threading.RLock()
+            return lk
+
+    class _All:
+        def __init__(self, owner):
+            self.owner, self.held = owner, []
+
+        def __enter__(self):
+            # With back-off: a thread that already holds ONE device's lock (a replay whose garbage collection runs a model
+            # destructor, which comes here) may be waiting for `_all` while the holder of `_all` waits for that device -- so a
+            # holder that cannot get a device lock within 50 ms lets go of everything and starts over.
+            n = max(torch.cuda.device_count() if torch.cuda.is_available() else 0, 1)
+            while True:
+                self.owner._all.acquire()
+                for i in range(n):
+                    lk = self.owner.device(i)
+                    if not lk.acquire(timeout=0.05):
+                        break
+                    self.held.append(lk)
+                else:
+                    return self
+                for lk in reversed(self.held):
+                    lk.release()
+                self.held = []
+                self.owner._all.release()
+                time.sleep(0.001)
+
+        def __exit__(self, *exc):
+            for lk in reversed(self.held):
+                lk.release()
+            self.held = []
+            self.owner._all.release()
+            return False
+
+    def all(self):
+        return _DeviceLocks._All(self)
+
+
+_locks = _DeviceLocks()
 
 
 class GraphedPipeline:
@@ -40,16 +97,18 @@ class GraphedPipeline:
         # the model by reference count
         self._det, self._ref = weakref.ref(det), (None if ref is None else weakref.ref(ref))
         self.batch, self.h, self.w, self.kmax, self.bgr = batch, height, width, kmax, bgr
+        self.pool = batch * kmax
+        self._lock = _locks.device(self.dev.index)
+        self.graph = None
         L = _lib.lib()
         shape = (batch, height, width, 3) if bgr else (batch, height, width)
-        n_out = packed_len(batch, kmax)
+        n_out = packed_len(batch, self.pool)
         with torch.cuda.device(self.dev):
             self.pin_in = torch.empty(shape, dtype=torch.uint8).pin_memory()
             self.dev_in = torch.empty(shape, dtype=torch.uint8, device=self.dev)
-            self.gray = torch.empty((batch, height, width), dtype=torch.uint8, device=self.dev) if bgr else self.dev_in
             self.out_dev = torch.empty((n_out,), dtype=torch.int32, device=self.dev)
             self.pin_out = torch.empty((n_out,), dtype=torch.int32).pin_memory()
-            nbytes = L.dcx_pipeline_workspace_bytes(det.handle, ref.handle if ref else None, batch, height, width, kmax)
+            nbytes = L.dcx_pipeline_workspace_bytes(det.handle, ref.handle if ref else None, batch, height, width, self.pool)
             if nbytes == 0:
                 raise ValueError("bad batch/shape for dcx_pipeline_workspace_bytes")
             self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
@@ -69,8 +128,8 @@ class GraphedPipeline:
     @property
     def deepc(self):
         det = self._det()
-        if det is None:
-            raise RuntimeError("the detector this graph was captured with has been destroyed")
+        if det is None:      # ReferenceError, not RuntimeError: infer_image treats RuntimeError as "capture failed, go eager"
+            raise ReferenceError("the detector this graph was captured with has been destroyed")
         return det
 
     @property
@@ -79,37 +138,63 @@ class GraphedPipeline:
             return None
         ref = self._ref()
         if ref is None:
-            raise RuntimeError("the RefineNet this graph was captured with has been destroyed")
+            raise ReferenceError("the RefineNet this graph was captured with has been destroyed")
         return ref
 
     def _enqueue(self) -> None:
         self.dev_in.copy_(self.pin_in, non_blocking=True)
-        if self.bgr:
-            _lib.check(_lib.lib().dcx_bgr2gray(self.dev_in.data_ptr(), self.h * self.w * 3, self.w * 3, self.batch, self.h,
-                                               self.w, self.gray.data_ptr(), _lib.current_stream()), "dcx_bgr2gray")
-        infer_batch_device(self.gray, self.dust_bin_ids, self.deepc, self.refinenet, self.kmax, out=self.out_dev, ws=self.ws)
+        # BGR frames: the conversion of inference.py:40 happens in the first layer's load (DCX_PIX_BGR8), no separate kernel
+        infer_batch_device(self.dev_in, self.dust_bin_ids, self.deepc, self.refinenet, out=self.out_dev, ws=self.ws, pool=self.pool)
         self.pin_out.copy_(self.out_dev, non_blocking=True)
 
     def run(self, frames: np.ndarray) -> List[np.ndarray]:
         """frames: (B,H,W,3) BGR or (B,H,W) gray uint8 host array (as configured) -> list of B keypoint arrays."""
-        if frames.shape != self._in_np.shape or frames.dtype != np.uint8:
-            raise ValueError(f"expected uint8 frames of shape {self._in_np.shape}, got {frames.dtype} {frames.shape}")
-        with _graph_lock:                                     # one capture / replay at a time per process
-            np.copyto(self._in_np, frames)
+        with self._lock:                                      # one replay at a time per GPU (a capture holds every GPU's lock)
+            graph, in_np, out_np = self.graph, self._in_np, self._out_np
+            if graph is None:
+                raise ReferenceError("this GraphedPipeline has been closed (its models were released)")
+            if frames.shape != in_np.shape or frames.dtype != np.uint8:
+                raise ValueError(f"expected uint8 frames of shape {in_np.shape}, got {frames.dtype} {frames.shape}")
+            np.copyto(in_np, frames)
             with torch.cuda.device(self.dev):
-                self.graph.replay()
+                graph.replay()
                 torch.cuda.current_stream().synchronize()
-            res, counts = unpack_results(self._out_np, self.batch, self.kmax, self.refinenet is not None)
-            if int(counts.max()) > self.kmax:                 # rare: capacity exceeded -> exact eager re-run
-                gray = frames if not self.bgr else self.gray.cpu().numpy()
-                res = infer_batch(gray, self.dust_bin_ids, self.deepc, self.refinenet, kmax=self.kmax)
+            res, counts = unpack_results(out_np, self.batch, self.pool, self.refinenet is not None)
+            need = int(counts.astype(np.int64).sum())
+            if need > self.pool:                              # rare: more corners than the captured pool -> exact eager re-run
+                res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need)
         return res
+
+    def close(self) -> None:
+        """Retire the pipeline: later ``run`` calls raise ReferenceError.  Never blocks and never destroys anything itself -- the
+        hipGraph and the buffers move to a graveyard that is emptied only by a thread holding the locks of ALL devices
+        (``_drain``), so hipGraphExecDestroy / hipFree can not overlap a replay or a capture, whichever thread drops the last
+        reference (``__del__`` comes here too) and whatever that thread is in the middle of."""
+        graph = getattr(self, "graph", None)
+        if graph is None:
+            return
+        self.graph = None
+        _graveyard.append((graph, self.ws, self.dev_in, self.out_dev, self.pin_in, self.pin_out, self.stream))
+        self.ws = self.dev_in = self.out_dev = self.pin_in = self.pin_out = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _CACHE_MAX = 8        # per detector: graphs pin ~25 MB of workspace per 320x240 shape
 _cache_lock = threading.RLock()         # re-entrant: dropping a pipeline may run model destructors that come back here
-_graph_lock = threading.RLock()          # serialises hipGraph capture AND replay (+ the synchronise that follows) process-wide
+_graph_lock = _locks.all                # `with _graph_lock():` = every device's lock (capture, destruction, cache surgery)
+_graveyard: list = []                   # hipGraphs / buffers of closed pipelines; list.append / pop are atomic
 _caches: "weakref.WeakSet" = weakref.WeakSet()     # the per-detector caches that exist (for clear_graph_cache())
+
+
+def _drain() -> None:
+    """Destroy what closed pipelines left behind.  Call with ``_graph_lock()`` held: no replay or capture is in flight anywhere."""
+    while _graveyard:
+        _graveyard.pop()
 
 
 class _Cache(dict):
@@ -123,10 +208,16 @@ def graphs_usable() -> bool:
     return not (L.dcx_get_timing() or L.dcx_profile_enabled())
 
 
+def _retire(victims) -> None:
+    for v in victims:
+        if v is not None:
+            v.close()
+
+
 def clear_graph_cache(deepc=None) -> None:
     """Drop the captured graphs (and their pinned / workspace buffers) of one detector, or of all of them."""
-    with _graph_lock:                   # destruction (hipGraphExecDestroy, hipFree of the workspace) never overlaps a replay / capture
-        victims = []                    # ... but happens outside _cache_lock; lock order is always _graph_lock -> _cache_lock
+    with _graph_lock():                 # lock order is always device locks -> _cache_lock
+        victims = []
         with _cache_lock:
             if deepc is not None:
                 det = deepc.model if hasattr(deepc, "model") else deepc
@@ -137,55 +228,81 @@ def clear_graph_cache(deepc=None) -> None:
                 if c:
                     victims.extend(c.values())
                     c.clear()
+        _retire(victims)
         del victims
+        _drain()
 
 
 def drop_graphs_of_detector(det) -> None:
     """Called when a detector releases its C handle: its graphs hold pointers into the freed weights."""
-    with _graph_lock:
+    if not getattr(det, "_graph_cache", None):      # nothing captured with it (checked unlocked: the caller owns the detector)
+        return
+    with _graph_lock():
         victims = []
         with _cache_lock:
             cache = getattr(det, "_graph_cache", None)
             if cache:
                 victims = list(cache.values())
                 cache.clear()
+        _retire(victims)
         del victims
+        _drain()
 
 
 def drop_graphs_of_refiner(ref) -> None:
     """Called when a RefineNet releases its C handle (reload / ``to(device)`` / destruction): graphs captured with it hold
     pointers into the freed weights."""
-    with _graph_lock:
+    with _cache_lock:
+        if not any(k[0] is not None and k[0][0] == id(ref) for c in list(_caches) for k in c):
+            return
+    with _graph_lock():
         victims = []
         with _cache_lock:
             for c in list(_caches):
                 for k in [k for k in c if k[0] is not None and k[0][0] == id(ref)]:
                     victims.append(c.pop(k, None))
+        _retire(victims)
         del victims
+        _drain()
 
 
 def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int, bgr: bool,
                     kmax: int = DEFAULT_KMAX) -> Optional[GraphedPipeline]:
     """One graph per (model pair, shape, library mode) for ``infer_image``, shared by all threads.  The cache lives ON the detector
     object (a small LRU) and its pipelines refer back to the models weakly, so graphs die with the model (by reference count)
-    instead of pinning it in a module-global table, and a re-allocated model can never alias a cached graph of a freed one."""
+    instead of pinning it in a module-global table, and a re-allocated model can never alias a cached graph of a freed one.
+    A hit costs one dictionary operation under the cache lock; only a miss (capture) takes the locks of all devices.  An evicted
+    pipeline that another thread is still holding keeps working until that thread lets go of it."""
     det = deepc.model if hasattr(deepc, "model") else deepc
     ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
     key = (None if ref is None else (id(ref), ref.handle.value), dust_bin_ids, height, width, bgr, kmax,
            int(_lib.lib().dcx_get_deterministic()))
-    with _graph_lock:                                         # capture excludes every replay (and other captures)
+
+    def lookup():
+        cache = getattr(det, "_graph_cache", None)
+        if cache is None:
+            cache = det._graph_cache = _Cache()
+            _caches.add(cache)
+        p = cache.pop(key, None)
+        if p is not None:
+            cache[key] = p                                    # most recently used last
+        return cache, p
+
+    with _cache_lock:
+        cache, p = lookup()
+    if p is not None:
+        return p
+    with _graph_lock():                                       # capture excludes every replay on every GPU (and other captures)
+        _drain()
         with _cache_lock:
-            cache = getattr(det, "_graph_cache", None)
-            if cache is None:
-                cache = det._graph_cache = _Cache()
-                _caches.add(cache)
-            p = cache.pop(key, None)
+            cache, p = lookup()                               # another thread may have captured it meanwhile
         if p is None:
             p = GraphedPipeline(dust_bin_ids, deepc, refinenet, 1, height, width, kmax, bgr)
-        evicted = []
-        with _cache_lock:
-            while len(cache) >= _CACHE_MAX:
-                evicted.append(cache.pop(next(iter(cache))))
-            cache[key] = p
-        del evicted                                           # destroyed under _graph_lock, outside _cache_lock
+            evicted = []
+            with _cache_lock:
+                while len(cache) >= _CACHE_MAX:
+                    evicted.append(cache.pop(next(iter(cache))))
+                cache[key] = p
+            del evicted           # not closed: a thread that still holds one finishes its call; __del__ retires it afterwards
+            _drain()
     return p

@@ -21,7 +21,7 @@ from .models.model_utils import extract_patches, pre_bgr_image, pred_to_keypoint
 from .models.net import dcModel, lModel
 from .models.refinenet import RefineNet, lRefineNet
 
-__all__ = ["load_models", "infer_image", "infer_image_staged", "infer_batch", "infer_batch_device",
+__all__ = ["load_models", "infer_image", "infer_image_staged", "infer_batch", "infer_batch_device", "unpack_results", "packed_len",
            "solve_pnp", "solve_pnp_batch", "solve_pnp_submit", "set_deterministic", "InferenceModel"]
 
 DEFAULT_KMAX = 64
@@ -126,110 +126,156 @@ def _unwrap(deepc, refinenet):
     return det, ref
 
 
+PIXEL_FORMATS = {"gray": 0, "opencv4": 1, "legacy14": 2}       # DCX_PIX_GRAY8 / DCX_PIX_BGR8 / DCX_PIX_BGR8_LEGACY14
+
+
+def packed_len(batch: int, pool: int, conf: bool = False) -> int:
+    """int32 words of the packed result of a batch: counts[B] | starts[B] | rows[pool][4] | xy[pool][2] (| conf[pool][2])."""
+    return 2 * batch + (8 if conf else 6) * pool
+
+
 def infer_batch_device(frames: torch.Tensor, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX,
-                       out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Enqueue detect+refine for a batch of GPU-resident gray frames; no host synchronisation.
+                       out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, pool: Optional[int] = None,
+                       conf: bool = False, bgr_variant: str = "opencv4") -> torch.Tensor:
+    """Enqueue detect+refine for a batch of GPU-resident frames; no host synchronisation.
+
+    frames: (B,H,W) uint8 gray, or (B,H,W,3) uint8 BGR (what the reference's callers hold, pose_estimation.py:53-59; the
+    ``cv2.cvtColor`` of inference.py:40 then happens inside the first layer's load, ``bgr_variant`` = which fixed-point
+    constants, see imgproc.py), contiguous, on the model's GPU.
+
+    The result is the batch's CORNER POOL: like the reference (inference.py:51-57) every firing cell of a frame is refined --
+    there is no per-frame cap; the only capacity is the pool of the whole batch, ``pool`` slots (default ``B * kmax``: ``kmax``
+    is the AVERAGE number of corners per frame the buffers are sized for).  One flat int32 tensor on the GPU, one allocation so
+    that one D2H (or one all-gather) moves everything:
+        [0, B)                counts[b]   firing cells of frame b (never truncated)
+        [B, 2B)               starts[b]   first pool slot of frame b (frames sit in the pool in the order they finished)
+        [2B, 2B + 4 pool)     rows[p]     (x, y, id, cell), frame b's in raster order at p = starts[b] + k
+        [.., + 2 pool)        xy[p]       refined (x, y) as float32 bit patterns (if refinenet)
+        [.., + 2 pool)        conf[p]     (``conf=True``) soft-max probability of the winning loc / ids class, float32 bits
+    Slots >= pool are dropped; ``sum(counts) > pool`` tells the caller to re-run with a larger pool.  Use ``unpack_results``.
 
     Scratch memory: by default a buffer owned by the detector object and keyed by the current HIP stream (so several
     streams / threads may drive one model pair concurrently, each on its own stream); pass ``ws`` (uint8 GPU tensor of
     at least ``dcx_pipeline_workspace_bytes`` bytes) to manage it yourself.  ``out`` (optional) must be a contiguous
-    int32 tensor of exactly ``packed_len`` elements on the model's GPU.
-
-    frames: (B,H,W) uint8 on the GPU.  Returns the packed result tensor (flat int32, on the GPU), one
-    allocation so that one D2H (or one all-gather) moves everything:
-        [0, B)                      counts[b]      firing cells of frame b (may exceed kmax)
-        [B, B + 4*B*kmax)           rows[b][k]     (x, y, id, cell) of the k-th corner, raster order
-        [B + 4*B*kmax, B + 6*B*kmax) xy[b][k]      refined (x, y) as float32 bit patterns (if refinenet)
-    Entries k >= min(counts[b], kmax) are unspecified.  Use ``unpack_results`` on the host.
+    int32 tensor of exactly ``packed_len(B, pool, conf)`` elements on the model's GPU.
     """
     det, ref = _unwrap(deepc, refinenet)
     dev = det.device
-    if frames.device != dev or frames.dtype != torch.uint8 or frames.ndim != 3 or not frames.is_contiguous():
-        raise ValueError("frames must be a contiguous (B,H,W) uint8 tensor on the model's GPU")
-    b, h, w = frames.shape
+    if (not isinstance(frames, torch.Tensor) or frames.device != dev or frames.dtype != torch.uint8 or not frames.is_contiguous()
+            or not (frames.ndim == 3 or (frames.ndim == 4 and frames.shape[3] == 3))):
+        raise ValueError("frames must be a contiguous (B,H,W) gray or (B,H,W,3) BGR uint8 tensor on the model's GPU")
+    b, h, w = frames.shape[:3]
+    bpp = 1 if frames.ndim == 3 else 3
+    if bgr_variant not in ("opencv4", "legacy14"):
+        raise ValueError(f"unknown BGR->gray variant {bgr_variant!r}")
+    pix = PIXEL_FORMATS["gray" if bpp == 1 else bgr_variant]
+    if pool is None:
+        pool = b * kmax
+    if pool <= 0:
+        raise ValueError("pool must be positive")
     L = _lib.lib()
     with torch.cuda.device(dev):
-        nbytes = L.dcx_pipeline_workspace_bytes(det.handle, ref.handle if ref else None, b, h, w, kmax)
+        nbytes = L.dcx_pipeline_workspace_bytes(det.handle, ref.handle if ref else None, b, h, w, pool)
         if nbytes == 0:
             raise ValueError("bad batch/shape for dcx_pipeline_workspace_bytes")
         if ws is None:
             ws = det._ws.get("pipe", dev, nbytes)
         elif ws.device != dev or ws.dtype != torch.uint8 or not ws.is_contiguous() or ws.numel() < nbytes:
             raise ValueError(f"ws must be a contiguous uint8 tensor of >= {nbytes} bytes on {dev}")
-        # outputs: counts [B] | rows [B,kmax,4] | xy [B,kmax,2], one allocation so one D2H moves all
-        n_i32 = b + b * kmax * 4 + b * kmax * 2
+        n_i32 = packed_len(b, pool, conf)
         if out is None:
             out = torch.empty((n_i32,), dtype=torch.int32, device=dev)
         elif out.device != dev or out.dtype != torch.int32 or out.numel() != n_i32 or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous int32 tensor of {n_i32} elements on {dev}")
         base = out.data_ptr()
-        counts_p, rows_p, xy_p = base, base + 4 * b, base + 4 * (b + b * kmax * 4)
-        _lib.check(L.dcx_infer_batch(det.handle, ref.handle if ref else None, frames.data_ptr(), h * w, w, b, h, w,
-                                     dust_bin_ids, kmax, ws.data_ptr(), ws.numel(), counts_p, rows_p,
-                                     xy_p if ref else None, _lib.current_stream()), "dcx_infer_batch")
+        counts_p, starts_p, rows_p = base, base + 4 * b, base + 8 * b
+        xy_p = rows_p + 16 * pool
+        conf_p = xy_p + 8 * pool
+        _lib.check(L.dcx_infer_batch(det.handle, ref.handle if ref else None, frames.data_ptr(), h * w * bpp, w * bpp, pix, b, h, w,
+                                     dust_bin_ids, pool, ws.data_ptr(), ws.numel(), counts_p, starts_p, rows_p,
+                                     xy_p if ref else None, conf_p if conf else None, _lib.current_stream()), "dcx_infer_batch")
     return out
 
 
-def unpack_results(packed: np.ndarray, batch: int, kmax: int, refined: bool) -> Tuple[List[np.ndarray], np.ndarray]:
+def unpack_results(packed: np.ndarray, batch: int, pool: int, refined: bool, conf: bool = False):
     """Host unpack of ``infer_batch_device``'s buffer -> per-frame arrays in infer_image's format.
 
     Per frame: (K,3) rows [x, y, id] sorted by id (stable w.r.t. raster order, inference.py:68-69);
-    float64 when refined, int64 otherwise; ``np.array([])`` when K == 0 (inference.py:51-52).
-    Also returns the raw counts (counts[b] > kmax means frame b overflowed the capacity).
-    """
+    float64 when refined, int64 otherwise; ``np.array([])`` when K == 0 (inference.py:51-52).  A frame whose corners did not
+    all fit the pool (only possible when ``counts.sum() > pool``) is returned as ``None``: the caller re-runs with a larger
+    pool.  Also returns the raw counts; with ``conf=True`` a third value, the per-frame (K,2) float32 arrays
+    [p_loc, p_ids] in the same (id-sorted) order."""
     packed = np.asarray(packed, dtype=np.int32)
     counts = packed[:batch]
-    rows = packed[batch:batch + batch * kmax * 4].reshape(batch, kmax, 4)
-    xy = packed[batch + batch * kmax * 4:].view(np.float32).reshape(batch, kmax, 2)
-    res: List[np.ndarray] = []
+    starts = packed[batch:2 * batch]
+    rows = packed[2 * batch:2 * batch + 4 * pool].reshape(pool, 4)
+    xy = packed[2 * batch + 4 * pool:2 * batch + 6 * pool].view(np.float32).reshape(pool, 2)
+    cf = packed[2 * batch + 6 * pool:2 * batch + 8 * pool].view(np.float32).reshape(pool, 2) if conf else None
+    res: List[Optional[np.ndarray]] = []
+    confs: List[Optional[np.ndarray]] = []
     for b in range(batch):
-        k = int(min(counts[b], kmax))
+        k, s0 = int(counts[b]), int(starts[b])
         if k == 0:
             res.append(np.array([]))
+            confs.append(np.zeros((0, 2), np.float32))
             continue
-        ids = rows[b, :k, 2].astype(np.int64)
+        if s0 + k > pool:
+            res.append(None)
+            confs.append(None)
+            continue
+        ids = rows[s0:s0 + k, 2].astype(np.int64)
         order = np.argsort(ids, kind="stable")
         if refined:
             a = np.empty((k, 3), np.float64)
-            a[:, 0:2] = xy[b, :k].astype(np.float64)
+            a[:, 0:2] = xy[s0:s0 + k].astype(np.float64)
         else:
             a = np.empty((k, 3), np.int64)
-            a[:, 0:2] = rows[b, :k, 0:2]
+            a[:, 0:2] = rows[s0:s0 + k, 0:2]
         a[:, 2] = ids
         res.append(a[order])
+        if conf:
+            confs.append(cf[s0:s0 + k][order].copy())
+    if conf:
+        return res, counts.copy(), confs
     return res, counts.copy()
 
 
-def infer_batch(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX):
-    """Batched infer_image: frames_gray (B,H,W) uint8 host array (or GPU tensor) -> list of B keypoint arrays.
+def _to_device_frames(frames, dev):
+    """(B,H,W) gray / (B,H,W,3) BGR uint8, host array or GPU tensor -> contiguous GPU tensor."""
+    if isinstance(frames, torch.Tensor):       # already on the GPU
+        d = frames
+    else:
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        d = torch.from_numpy(frames)
+    if d.dtype != torch.uint8 or not (d.ndim == 3 or (d.ndim == 4 and d.shape[3] == 3)):
+        raise ValueError("expected (B,H,W) uint8 gray frames or (B,H,W,3) uint8 BGR frames")
+    return d.to(dev).contiguous()
+
+
+def infer_batch(frames, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX, pool: Optional[int] = None,
+                conf: bool = False, bgr_variant: str = "opencv4"):
+    """Batched infer_image: (B,H,W) uint8 gray frames or (B,H,W,3) uint8 BGR frames (host array or GPU tensor) -> list of B
+    keypoint arrays (with ``conf=True``: ``(keypoints, confidences)``, per frame a (K,2) float32 array [p_loc, p_ids]).
 
     Frames are independent (the reference has no cross-frame state) and the kernel family of every layer depends on the
     layer only, so frame b's corners are bit-identical to ``infer_image`` on that frame alone, whatever the
-    batch size.  If a frame fires more than ``kmax`` cells the batch is re-run with a larger capacity (never silently
-    truncated).
-    """
+    batch size.  Every firing cell of every frame is refined, as in the reference (inference.py:51-57): a frame may fire any
+    number of cells; only if the WHOLE batch fires more than ``pool`` (default ``B * kmax``) cells is it run a second time, with
+    a pool of exactly the size the first pass reported (never silently truncated).  BGR frames are converted on the device with
+    the fixed-point formula of the OpenCV generation the reference pins (``bgr_variant``, see imgproc.py)."""
     det, _ = _unwrap(deepc, refinenet)
-    dev = det.device
-    if isinstance(frames_gray, torch.Tensor):       # already on the GPU (e.g. the output of imgproc.bgr2gray_device)
-        d_frames = frames_gray
-        if d_frames.ndim != 3 or d_frames.dtype != torch.uint8:
-            raise ValueError("expected (B,H,W) uint8 gray frames")
-        b, h, w = d_frames.shape
-    else:
-        frames_gray = np.ascontiguousarray(frames_gray, dtype=np.uint8)
-        if frames_gray.ndim != 3:
-            raise ValueError("expected (B,H,W) uint8 gray frames")
-        b, h, w = frames_gray.shape
-        d_frames = torch.from_numpy(frames_gray).to(dev)
-    cells = (h // 8) * (w // 8)
+    d_frames = _to_device_frames(frames, det.device)
+    b = d_frames.shape[0]
+    if pool is None:
+        pool = b * kmax
     while True:
-        packed = infer_batch_device(d_frames, dust_bin_ids, deepc, refinenet, kmax).cpu().numpy()
-        res, counts = unpack_results(packed, b, kmax, refinenet is not None)
-        if int(counts.max()) <= kmax:
-            return res
-        new_kmax = min(cells, max(2 * kmax, int(counts.max())))
-        warnings.warn(f"a frame produced {int(counts.max())} corners > kmax={kmax}; re-running with kmax={new_kmax}")
-        kmax = new_kmax
+        packed = infer_batch_device(d_frames, dust_bin_ids, deepc, refinenet, pool=pool, conf=conf, bgr_variant=bgr_variant).cpu().numpy()
+        out = unpack_results(packed, b, pool, refinenet is not None, conf)
+        need = int(out[1].astype(np.int64).sum())
+        if need <= pool:
+            return (out[0], out[2]) if conf else out[0]
+        warnings.warn(f"the batch produced {need} corners > pool={pool}; re-running with pool={need}")
+        pool = need
 
 
 _graph_state = {"enabled": None, "warned": False}
@@ -248,7 +294,13 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
     One frame per call is the reference's own protocol (benchmark.py:37-53), so this path is built for call latency:
     the whole call -- upload, BGR->gray, both networks, decode, download -- is one hipGraph replay per image shape
     (``graph.GraphedPipeline``; ``DCX_GRAPH=0`` keeps the eager launches).  BGR->gray runs through OpenCV on the host when
-    cv2 is importable (what the reference calls), otherwise on the device with the same fixed-point formula."""
+    cv2 is importable (what the reference calls), otherwise on the device, inside the first layer's load, with the fixed-point
+    formula of the OpenCV generation the reference pins.
+
+    ``draw_pred=True`` is a debugging aid and a SLOW path: the reference also draws the UNREFINED detections, which only the
+    staged path (``infer_image_staged``: host BGR->gray, no graph, the reference's three host syncs) has at hand; drawing needs
+    OpenCV (ImportError without it, unless the frame has no detections: then the copy is returned undrawn, as the reference's
+    helper would)."""
     require_cuda(device)
     from .imgproc import _opencv
     if not isinstance(img, np.ndarray) or img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
@@ -256,17 +308,14 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
     if draw_pred:      # debugging aid: the reference draws the UNREFINED detections too, which only the staged path has at hand
         return infer_image_staged(img, dust_bin_ids, deepc, refinenet, True, device)
     keypoints = None
+    frame = bgr2gray(img)[None] if _opencv() else img[None]       # cv2 on the host (what the reference calls), else on the device
     from .graph import graphs_usable
     if _graphs_enabled() and graphs_usable():
         try:
             from .graph import cached_pipeline
-            if _opencv():
-                pipe = cached_pipeline(dust_bin_ids, deepc, refinenet, img.shape[0], img.shape[1], bgr=False)
-                keypoints = pipe.run(bgr2gray(img)[None])[0]
-            else:
-                pipe = cached_pipeline(dust_bin_ids, deepc, refinenet, img.shape[0], img.shape[1], bgr=True)
-                keypoints = pipe.run(img[None])[0]
-        except (_lib.DcxError, ValueError):
+            pipe = cached_pipeline(dust_bin_ids, deepc, refinenet, img.shape[0], img.shape[1], bgr=frame.ndim == 4)
+            keypoints = pipe.run(frame)[0]
+        except (_lib.DcxError, ValueError, ReferenceError):
             raise
         except RuntimeError as e:      # graph capture unavailable: same kernels, launched eagerly
             if not _graph_state["warned"]:
@@ -274,13 +323,7 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
                 _graph_state["warned"] = True
             _graph_state["enabled"] = False
     if keypoints is None:
-        if _opencv():
-            keypoints = infer_batch(bgr2gray(img)[None], dust_bin_ids, deepc, refinenet)[0]
-        else:
-            from .imgproc import bgr2gray_device
-            det, _ = _unwrap(deepc, refinenet)
-            d_gray = bgr2gray_device(torch.from_numpy(np.ascontiguousarray(img)).to(det.device))
-            keypoints = infer_batch(d_gray[None], dust_bin_ids, deepc, refinenet)[0]
+        keypoints = infer_batch(frame, dust_bin_ids, deepc, refinenet)[0]
     return keypoints, img
 
 
@@ -295,8 +338,9 @@ def infer_image_staged(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None
     img_gray = torch.tensor(img_gray, device=device)
     loc_hat, ids_hat = deepc.infer_image(img_gray)
     keypoints, ids_found = pred_to_keypoints(loc_hat, ids_hat, dust_bin_ids)
-    if draw_pred:
-        img = draw_inner_corners(img, keypoints.cpu().numpy(), ids_found.cpu().numpy(), radius=3, draw_ids=True, color=(0, 0, 255))
+    if draw_pred:      # nothing to draw on a frame without detections: the reference's helper returns the copy (aruco_utils.py:175)
+        img = (draw_inner_corners(img, keypoints.cpu().numpy(), ids_found.cpu().numpy(), radius=3, draw_ids=True, color=(0, 0, 255))
+               if ids_found.shape[0] else img.copy())
     if ids_found.shape[0] == 0:
         return np.array([]), img
     if refinenet is not None:
@@ -344,5 +388,6 @@ class InferenceModel:
     def infer_image(self, img: np.ndarray, draw_pred: bool = False):
         return infer_image(img, self.n_ids, self.deepc, self.refinenet, draw_pred, self.device)
 
-    def infer_batch(self, frames_gray: np.ndarray, kmax: int = DEFAULT_KMAX):
-        return infer_batch(frames_gray, self.n_ids, self.deepc, self.refinenet, kmax)
+    def infer_batch(self, frames: np.ndarray, kmax: int = DEFAULT_KMAX, conf: bool = False):
+        """(B,H,W) gray or (B,H,W,3) BGR uint8 frames -> list of keypoint arrays (``conf=True``: also the confidences)."""
+        return infer_batch(frames, self.n_ids, self.deepc, self.refinenet, kmax, conf=conf)

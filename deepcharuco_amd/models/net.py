@@ -6,6 +6,7 @@ Only the inference surface exists: ``forward`` / ``__call__`` / ``infer_image`` 
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import Optional, Tuple
 
 import torch
@@ -64,11 +65,15 @@ class dcModel:
 
     def _release(self):
         if self._handle is not None:
-            if getattr(self, "_graph_cache", None):          # hipGraphs captured with this handle's weights (graph.py)
-                from ..graph import drop_graphs_of_detector
-                drop_graphs_of_detector(self)                # under the graph lock, then the cache lock (same order as everywhere)
-            _lib.lib().dcx_detector_destroy(self._handle)
-            self._handle = None
+            try:
+                # hipGraphs captured with this handle's weights (graph.py).  sys.modules, not an import: this runs from __del__,
+                # possibly during interpreter shutdown, where an import can fail -- and the handle must be freed regardless
+                g = sys.modules.get("deepcharuco_amd.graph")
+                if g is not None:
+                    g.drop_graphs_of_detector(self)          # device locks first, then the cache lock (same order as everywhere)
+            finally:
+                _lib.lib().dcx_detector_destroy(self._handle)
+                self._handle = None
 
     def __del__(self):
         try:

@@ -5,7 +5,11 @@ The reference has no multi-device code; frames are indep
 embarrassingly: rank r of R owns frames [lo, hi) and runs the whole detect+refine pipeline on
 them.  The only collective is one ``all_gather_into_tensor`` of the fixed-shape packed corner
 buffer per batch (RCCL over xGMI with backend "nccl"; "gloo" for the CPU tests).  The payload
-is KB-scale (B/R * (1 + 6*kmax) int32), i.e. latency-bound, so it is sent as ONE fused buffer.
+is KB-scale (B/R * (2 + 6*kmax) int32), i.e. latency-bound, so it is sent as ONE fused buffer.
+
+Every rank's buffer is a corner POOL of ``pool = ceil(B/R) * kmax`` slots (inference.infer_batch_device): a frame may fire any
+number of cells; only a rank whose whole shard fires more than its pool overflows, and then ALL ranks (they all see all counts
+after the gather) run that batch again with a pool of the size the first pass reported -- nothing is truncated, nothing raises.
 """
 from __future__ import annotations
 
@@ -15,7 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .inference import unpack_results
+from .inference import packed_len, unpack_results  # noqa: F401  (packed_len is re-exported: callers size buffers with it)
 
 
 def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
@@ -27,20 +31,15 @@ def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def packed_len(batch: int, kmax: int) -> int:
-    return batch + batch * kmax * 4 + batch * kmax * 2
-
-
-def pad_packed(packed: torch.Tensor, batch: int, kmax: int, batch_max: int) -> torch.Tensor:
-    """Re-lay a rank's packed buffer [counts|rows|xy] for ``batch`` frames into the layout for
-    ``batch_max`` frames (missing frames get count 0) so every rank contributes the same shape."""
+def pad_packed(packed: torch.Tensor, batch: int, pool: int, batch_max: int) -> torch.Tensor:
+    """Re-lay a rank's packed buffer [counts|starts|rows|xy] for ``batch`` frames into the layout for ``batch_max`` frames with
+    the same pool (missing frames get count 0) so every rank contributes the same shape."""
     if batch == batch_max:
         return packed
-    out = torch.zeros(packed_len(batch_max, kmax), dtype=packed.dtype, device=packed.device)
+    out = torch.zeros(packed_len(batch_max, pool), dtype=packed.dtype, device=packed.device)
     out[:batch] = packed[:batch]
-    r0, r1 = batch, batch + batch * kmax * 4
-    out[batch_max:batch_max + batch * kmax * 4] = packed[r0:r1]
-    out[batch_max + batch_max * kmax * 4:batch_max + batch_max * kmax * 4 + batch * kmax * 2] = packed[r1:]
+    out[batch_max:batch_max + batch] = packed[batch:2 * batch]
+    out[2 * batch_max:] = packed[2 * batch:]
     return out
 
 
@@ -146,26 +145,32 @@ class OverlappedGather:
         return self.host[s].numpy().copy()
 
 
-def unpack_gathered(gathered: np.ndarray, n_frames: int, world: int, kmax: int, refined: bool):
-    """Host side: (R, len) gathered buffers -> list of n_frames keypoint arrays in global frame order."""
+def unpack_gathered(gathered: np.ndarray, n_frames: int, world: int, pool: int, refined: bool):
+    """Host side: (R, len) gathered buffers (each laid out for ceil(n/R) frames and ``pool`` slots) -> (list of n_frames keypoint
+    arrays in global frame order -- ``None`` for frames of a rank whose pool overflowed --, counts (n_frames,), the largest number
+    of corners any ONE rank produced: > pool means "run again with at least that pool")."""
     batch_max = shard_range(n_frames, 0, world)[1]
     res: List[np.ndarray] = []
     counts_all = []
+    need = 0
     for r in range(world):
         lo, hi = shard_range(n_frames, r, world)
-        rr, cc = unpack_results(gathered[r], batch_max, kmax, refined)
+        rr, cc = unpack_results(gathered[r], batch_max, pool, refined)
         res.extend(rr[:hi - lo])
         counts_all.extend(cc[:hi - lo].tolist())
-    return res, np.asarray(counts_all, np.int32)
+        need = max(need, int(cc[:hi - lo].astype(np.int64).sum()))
+    return res, np.asarray(counts_all, np.int32), need
 
 
 def infer_frames_sharded(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, kmax: int = 64,
-                         group=None, run_local=None):
+                         group=None, run_local=None, pool: Optional[int] = None):
     """Collective version of ``inference.infer_batch``: every rank passes the same (B,H,W) host
     array (or at least its own slice), processes frames [lo,hi) and receives ALL results.
 
-    ``run_local(frames_slice) -> packed int32 tensor`` defaults to the HIP pipeline; the gloo CPU
+    ``run_local(frames_slice, pool) -> packed int32 tensor`` defaults to the HIP pipeline; the gloo CPU
     tests inject a stand-in so that the sharding / packing / exchange logic is covered without a GPU.
+    ``pool`` = corner slots per rank (default ceil(B/R) * kmax).  If some rank's shard fires more cells than that, every rank
+    sees it in the gathered counts and all of them repeat the call with the pool the first pass asked for.
     """
     from .inference import infer_batch_device  # local import: needs the GPU library
     world = dist.get_world_size(group)
@@ -173,28 +178,28 @@ def infer_frames_sharded(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refi
     n = frames_gray.shape[0]
     lo, hi = shard_range(n, rank, world)
     batch_max = shard_range(n, 0, world)[1]
+    if pool is None:
+        pool = max(1, batch_max * kmax)
     if run_local is None:
         det = deepc.model if hasattr(deepc, "model") else deepc
 
-        def run_local(fr):
+        def run_local(fr, pool_):
             d = torch.from_numpy(np.ascontiguousarray(fr)).to(det.device)
-            return infer_batch_device(d, dust_bin_ids, deepc, refinenet, kmax)
-    if hi > lo:
-        packed = run_local(frames_gray[lo:hi])
-    else:
-        packed = None
+            return infer_batch_device(d, dust_bin_ids, deepc, refinenet, pool=pool_)
     host_exchange = dist.get_backend(group) == "gloo"        # gloo (CPU tests, several ranks on one GPU): through host memory
-    if packed is None:
-        dev = "cpu" if host_exchange else torch.device("cuda", torch.cuda.current_device())
-        packed = torch.zeros(packed_len(0, kmax), dtype=torch.int32, device=dev)
-    elif host_exchange and packed.device.type != "cpu":
-        packed = packed.cpu()
-    packed = pad_packed(packed, hi - lo, kmax, batch_max)
-    gathered, _ = gather_packed(packed, group)
-    res, counts = unpack_gathered(gathered.cpu().numpy(), n, world, kmax, refinenet is not None)
-    if int(counts.max(initial=0)) > kmax:
-        raise RuntimeError(f"a frame fired {int(counts.max())} cells > kmax={kmax}; raise kmax")
-    return res
+    while True:
+        packed = run_local(frames_gray[lo:hi], pool) if hi > lo else None
+        if packed is None:
+            dev = "cpu" if host_exchange else torch.device("cuda", torch.cuda.current_device())
+            packed = torch.zeros(packed_len(0, pool), dtype=torch.int32, device=dev)
+        elif host_exchange and packed.device.type != "cpu":
+            packed = packed.cpu()
+        packed = pad_packed(packed, hi - lo, pool, batch_max)
+        gathered, _ = gather_packed(packed, group)
+        res, counts, need = unpack_gathered(gathered.cpu().numpy(), n, world, pool, refinenet is not None)
+        if need <= pool:
+            return res
+        pool = need        # the same number on every rank: the repeat is collective
 
 
 def infer_batches_sharded(batches, dust_bin_ids: int, deepc, refinenet=None, kmax: int = 64, group=None,
@@ -204,15 +209,24 @@ def infer_batches_sharded(batches, dust_bin_ids: int, deepc, refinenet=None, kma
 
     Batch i+1's upload and kernels are enqueued before batch i's gathered corner lists are waited for, and the gather
     itself runs on :class:`OverlappedGather`'s side stream, so the exchange step costs no GPU time on the compute
-    stream.  Ranks with fewer frames than rank 0 (ragged split) pad with blank frames whose results are dropped."""
+    stream.  Ranks with fewer frames than rank 0 (ragged split) pad with blank frames whose results are dropped.
+    Capacity: every rank's corner pool holds ceil(B/R) * kmax corners for its whole shard (no per-frame cap); a batch on which
+    some rank needs more is repeated by all ranks with :func:`infer_frames_sharded` at the pool the first pass reported."""
     from .inference import infer_batch_device  # local import: needs the GPU library
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = backend or dist.get_backend(group)
     det = deepc.model if hasattr(deepc, "model") else deepc
     dev = det.device
     og = None
-    pending = []          # (step index, n_frames)
+    pending = []          # (step index, frames)
     i = 0
+
+    def finish(step, frames_j):
+        res, _, need = unpack_gathered(og.result(step), frames_j.shape[0], world, pool, refinenet is not None)
+        if need > pool:       # every rank sees the same gathered counts, so every rank takes this branch
+            res = infer_frames_sharded(frames_j, dust_bin_ids, deepc, refinenet, group=group, pool=need)
+        return res
+
     for frames in batches:
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n, h, w = frames.shape
@@ -220,25 +234,19 @@ def infer_batches_sharded(batches, dust_bin_ids: int, deepc, refinenet=None, kma
         bmax = shard_range(n, 0, world)[1]
         if og is None:
             shape0 = (n, h, w)
-            og = OverlappedGather(packed_len(bmax, kmax), dev, group, backend, depth)
+            pool = max(1, bmax * kmax)
+            og = OverlappedGather(packed_len(bmax, pool), dev, group, backend, depth)
         elif (n, h, w) != shape0:
             raise ValueError("infer_batches_sharded needs batches of one shape; flush and start a new call")
         local = np.zeros((bmax, h, w), np.uint8)
         local[:hi - lo] = frames[lo:hi]
         if len(pending) == depth:                       # the slot about to be reused: hand its results out first
-            j, nj = pending.pop(0)
-            yield _unpack_step(og, j, nj, world, kmax, refinenet is not None)
+            j, fj = pending.pop(0)
+            yield finish(j, fj)
         d = torch.from_numpy(local).to(dev, non_blocking=True)
-        infer_batch_device(d, dust_bin_ids, deepc, refinenet, kmax, out=og.acquire(i))
+        infer_batch_device(d, dust_bin_ids, deepc, refinenet, out=og.acquire(i), pool=pool)
         og.launch(i)
-        pending.append((i, n))
+        pending.append((i, frames))
         i += 1
-    for j, nj in pending:
-        yield _unpack_step(og, j, nj, world, kmax, refinenet is not None)
-
-
-def _unpack_step(og: "OverlappedGather", step: int, n_frames: int, world: int, kmax: int, refined: bool):
-    res, counts = unpack_gathered(og.result(step), n_frames, world, kmax, refined)
-    if int(counts.max(initial=0)) > kmax:
-        raise RuntimeError(f"a frame fired {int(counts.max())} cells > kmax={kmax}; raise kmax")
-    return res
+    for j, fj in pending:
+        yield finish(j, fj)

@@ -17,30 +17,36 @@ from typing import Iterable, Iterator, List, Optional, Tuple
 import numpy as np
 import torch
 
-from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, solve_pnp_submit, unpack_results
-from .sharding import packed_len
+from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, packed_len, solve_pnp_submit, unpack_results
 
 
 class FrameStream:
     def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 32, height: int = 240,
                  width: int = 320, kmax: int = DEFAULT_KMAX, depth: int = 2, pnp: Optional[dict] = None,
-                 compute_streams: int = 1):
+                 compute_streams: int = 1, bgr: bool = False):
+        """``bgr=True``: the stream is fed (n,H,W,3) BGR frames, as the reference's callers hold them (pose_estimation.py:53-59);
+        the colour conversion of inference.py:40 happens on the device inside the first layer's load.  ``kmax``: the AVERAGE
+        number of corners per frame the buffers are sized for -- the corner pool of a batch holds ``batch * kmax`` corners and a
+        single frame may use any share of it."""
         det = deepc.model if hasattr(deepc, "model") else deepc
         self.dev = det.device
         self.dust_bin_ids, self.deepc, self.refinenet = dust_bin_ids, deepc, refinenet
         self.batch, self.h, self.w, self.kmax, self.depth = batch, height, width, kmax, depth
+        self.pool = batch * kmax
+        self.bgr = bool(bgr)
         self.pnp = pnp
         if not (1 <= compute_streams <= depth):
             raise ValueError("compute_streams must be between 1 and depth")
-        n_out = packed_len(batch, kmax)
+        n_out = packed_len(batch, self.pool)
+        shape = (batch, height, width, 3) if self.bgr else (batch, height, width)
         with torch.cuda.device(self.dev):
             self.copy_stream = torch.cuda.Stream()
             # compute_streams = 2: consecutive batches run the pipeline on alternating streams, so batch i+1's detector
             # kernels fill the CUs that batch i's small RefineNet launches / ramps / partial last rounds leave idle
             # (+7 % frames/s at bs=32, tools/two_stream_probe.py); the pipeline scratch is per (model, stream)
             self.compute = [torch.cuda.Stream() for _ in range(compute_streams)] if compute_streams > 1 else None
-            self.pin_in = [torch.empty((batch, height, width), dtype=torch.uint8).pin_memory() for _ in range(depth)]
-            self.dev_in = [torch.empty((batch, height, width), dtype=torch.uint8, device=self.dev) for _ in range(depth)]
+            self.pin_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+            self.dev_in = [torch.empty(shape, dtype=torch.uint8, device=self.dev) for _ in range(depth)]
             self.dev_out = [torch.empty((n_out,), dtype=torch.int32, device=self.dev) for _ in range(depth)]
             self.pin_out = [torch.empty((n_out,), dtype=torch.int32).pin_memory() for _ in range(depth)]
             self.ev_h2d = [torch.cuda.Event() for _ in range(depth)]
@@ -53,20 +59,23 @@ class FrameStream:
         ticket, n, frames = self._pending[slot]
         self._pending[slot] = None
         self.ev_done[slot].synchronize()
-        res, counts = unpack_results(self.pin_out[slot].numpy(), self.batch, self.kmax, self.refinenet is not None)
+        res, counts = unpack_results(self.pin_out[slot].numpy(), self.batch, self.pool, self.refinenet is not None)
         res = res[:n]
-        if n and int(counts[:n].max()) > self.kmax:      # rare: a frame exceeded the capacity -> exact re-run
-            res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, kmax=self.kmax)
+        need = int(counts.astype(np.int64).sum())
+        if need > self.pool:         # rare: the batch fired more cells than its pool holds -> exact re-run with the pool it asked for
+            res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need)
         if self.pnp is not None:     # host stage: futures now, resolved when the batch is handed out
             return ticket, res, solve_pnp_submit(res, **self.pnp)
         return ticket, res
 
     def submit(self, frames_gray: np.ndarray):
-        """Enqueue one batch (n <= batch frames). Returns the (ticket, results) of the batch that had to be retired to
-        make room, or None; with a PnP stage the tuple carries a third element, the per-frame ``solve_pnp`` futures."""
+        """Enqueue one batch (n <= batch frames; gray (n,H,W), or BGR (n,H,W,3) for a ``bgr=True`` stream). Returns the (ticket,
+        results) of the batch that had to be retired to make room, or None; with a PnP stage the tuple carries a third element,
+        the per-frame ``solve_pnp`` futures."""
         n = frames_gray.shape[0]
-        if n > self.batch or tuple(frames_gray.shape[1:]) != (self.h, self.w) or frames_gray.dtype != np.uint8:
-            raise ValueError("frames must be (n<=batch, H, W) uint8")
+        want = (self.h, self.w, 3) if self.bgr else (self.h, self.w)
+        if n > self.batch or tuple(frames_gray.shape[1:]) != want or frames_gray.dtype != np.uint8:
+            raise ValueError(f"frames must be (n<=batch, {', '.join(map(str, want))}) uint8")
         slot = self._ticket % self.depth
         retired = self._collect(slot) if self._pending[slot] is not None else None
         self.pin_in[slot][:n].numpy()[...] = frames_gray
@@ -80,8 +89,8 @@ class FrameStream:
                 self.ev_h2d[slot].record(self.copy_stream)
             with torch.cuda.stream(compute):
                 compute.wait_event(self.ev_h2d[slot])
-                infer_batch_device(self.dev_in[slot], self.dust_bin_ids, self.deepc, self.refinenet, self.kmax,
-                                   out=self.dev_out[slot])
+                infer_batch_device(self.dev_in[slot], self.dust_bin_ids, self.deepc, self.refinenet, out=self.dev_out[slot],
+                                   pool=self.pool)
                 self.ev_free[slot].record(compute)
                 self.pin_out[slot].copy_(self.dev_out[slot], non_blocking=True)
                 self.ev_done[slot].record(compute)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import weights as W
-from .inference import infer_batch_device, unpack_results
+from .inference import infer_batch_device
 from .models.net import dcModel
 
 # name -> per-GPU workload of a BASELINE.json config (configs[0] is the CPU plumbing case, not a GPU workload)
@@ -58,13 +58,14 @@ def _logits_on(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: int):
 
 
 def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: int = 16, per_frame: int = 16,
-                      diverse_ids: bool = False, kmax: int = 0) -> W.StateDict:
+                      diverse_ids: bool = False) -> W.StateDict:
     """Returns a copy of ``sd_dc`` whose ``convDb.bias[n_ids]`` makes ``per_frame * B`` cells fire on ``frames_dev``
     (HIP detector logits -> host numpy; the (k-th, k+1-th) largest non-dust-bin margins bracket the shift).
 
     ``diverse_ids``: first equalise ``convDb.bias[0:n_ids]`` per class (``weights.diverse_ids_bias_shift``) so that the firing
     cells carry all the ids of the board instead of the one or two a random-init ids head lets win everywhere.
-    ``kmax``: the pipeline's corner capacity per frame -- cells beyond it are not counted towards the target."""
+    (Round 4 had a ``kmax`` argument that stopped counting a frame's cells at the pipeline's per-frame capacity; the pipeline has
+    no per-frame capacity any more -- every firing cell is refined -- so the target is simply the number of firing cells.)"""
     sd = {k_: v.copy() for k_, v in sd_dc.items()}
     k = per_frame * frames_dev.shape[0]
     la, ids = _logits_on(sd, frames_dev, dev, n_ids)
@@ -76,20 +77,6 @@ def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: 
     mm = np.where(la == 64, -1e30, m)
     flat = mm.ravel()
     order = np.argsort(-flat, kind="stable")
-    if kmax > 0:
-        # the pipeline refines at most kmax corners per frame: count a frame's cells only up to kmax, so that the REFINED corners
-        # (what the FLOP count of the workload is based on) average per_frame exactly even when one frame fires more than kmax cells
-        frame_of = order // (flat.size // frames_dev.shape[0])
-        seen = np.zeros(frames_dev.shape[0], np.int64)
-        total, k_eff = 0, k
-        for j, f in enumerate(frame_of):
-            if seen[f] < kmax:
-                total += 1
-            seen[f] += 1
-            if total == k:
-                k_eff = j + 1
-                break
-        k = k_eff
     ms = flat[order]
     k = max(1, min(k, flat.size - 1))
     delta = np.float32((ms[k - 1] + ms[k]) / 2)
@@ -100,8 +87,8 @@ def calibrate_dustbin(sd_dc: W.StateDict, frames_dev: torch.Tensor, dev, n_ids: 
 def frame_counts(frames_dev: torch.Tensor, dc, dust_bin_ids: int = 16) -> np.ndarray:
     """Firing cells per frame, from the product pipeline itself (detector + decode, no RefineNet)."""
     b = frames_dev.shape[0]
-    packed = infer_batch_device(frames_dev, dust_bin_ids, dc, None, kmax=1)
-    return unpack_results(packed.cpu().numpy(), b, 1, False)[1]
+    packed = infer_batch_device(frames_dev, dust_bin_ids, dc, None, pool=1)     # counts are exact whatever the pool
+    return packed[:b].cpu().numpy().copy()
 
 
 def select_fixed_k_frames(kind: str, seed: int, batch: int, height: int, width: int, k: int, dc, dev,

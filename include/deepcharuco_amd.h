@@ -151,16 +151,34 @@ int dcx_refiner_forward(const dcx_refiner* rf, const float* d_patches, int max_p
 int dcx_argmax2d(const float* d_x, int k, int h, int w, int32_t* d_out, void* stream);
 
 /* ---- whole path for a batch: infer_image inference.py:32-70 without host syncs ----------
- * frames u8 -> rows/counts (detector+decode) -> patch table -> patches -> RefineNet -> xy.
- * d_xy f32 [B][kmax][2]; rows beyond counts[b] are untouched.  d_ws must hold
- * dcx_pipeline_workspace_bytes().  rf may be null (detector only; d_xy ignored).          */
+ * frames u8 -> detector -> per-cell arg-max + dust-bin rule -> ordered compaction -> RefineNet on every firing cell -> xy.
+ *
+ * Frames: DCX_PIX_GRAY8 (what inference.py:40 produces) or interleaved BGR (what infer_image is handed, inference.py:32; the
+ * conversion of dcx_bgr2gray / dcx_bgr2gray_legacy14 happens in the first layer's load, the gray frame is never stored);
+ * frame_stride and pitch in BYTES.
+ *
+ * Results -- the batch's CORNER POOL.  The reference refines every firing cell of a frame (inference.py:51-57, no cap), so
+ * there is no per-frame capacity: frame b's corners occupy the pool slots [d_starts[b], d_starts[b] + d_counts[b]) in raster
+ * order (torch.nonzero's, model_utils.py:112), whatever their number, as long as the BATCH fits: sum_b counts[b] <= pool.
+ *   d_counts int32 [B]        firing cells of frame b (never truncated)
+ *   d_starts int32 [B]        first pool slot of frame b; which frame comes first in the pool is unspecified
+ *   d_rows   int32 [pool][4]  (x, y, id, cell = cy*Wc + cx)
+ *   d_xy     f32   [pool][2]  RefineNet's corners_og (refinenet.py:114); required iff rf != NULL
+ *   d_conf   f32   [pool][2]  nullable: soft-max probability of the winning loc class (65-way) and ids class (n_ids+1-way) of
+ *                             the cell -- the "confidences" the docstring of pred_to_keypoints (model_utils.py:81-84) mentions;
+ *                             the reference never thresholds on them and neither does this library
+ * Slots >= pool are dropped: when sum(counts) > pool the caller re-runs with a larger pool (complete frames are still valid).
+ * d_ws must hold dcx_pipeline_workspace_bytes().  rf may be null (detector + decode only).                                */
+#define DCX_PIX_GRAY8          0
+#define DCX_PIX_BGR8           1   /* OpenCV 4.x 15-bit constants, = dcx_bgr2gray          */
+#define DCX_PIX_BGR8_LEGACY14  2   /* 14-bit constants,            = dcx_bgr2gray_legacy14 */
 size_t dcx_pipeline_workspace_bytes(const dcx_detector* det, const dcx_refiner* rf,
-                                    int batch, int height, int width, int kmax);
+                                    int batch, int height, int width, int pool);
 int dcx_infer_batch(const dcx_detector* det, const dcx_refiner* rf,
-                    const uint8_t* d_frames_u8, long frame_stride, int pitch,
-                    int batch, int height, int width, int dust_bin, int kmax,
+                    const uint8_t* d_frames_u8, long frame_stride, int pitch, int pixel_format,
+                    int batch, int height, int width, int dust_bin, int pool,
                     void* d_ws, size_t ws_bytes,
-                    int32_t* d_counts, int32_t* d_rows, float* d_xy, void* stream);
+                    int32_t* d_counts, int32_t* d_starts, int32_t* d_rows, float* d_xy, float* d_conf, void* stream);
 
 /* ---- stage-level entry point for kernel tests / roofline measurement -------------------
  * One 3x3 (or 1x1) convolution + bias [+ eval-BN + ReLU] [+ 2x2 max-pool] on C4 tensors
@@ -181,8 +199,8 @@ int dcx_c4_to_nchw(const float* d_c4, int n, int c, int h, int w, float* d_nchw,
 /* ---- instrumentation: per-stage device time of the last dcx_infer_batch() ---------------
  * When enabled, the pipeline records hipEvents on its stream around each stage; after the
  * stream has been synchronised by the caller, dcx_last_timings() returns milliseconds:
- * [0] detector conv stack, [1] fused tail (1x1 heads + arg-max) + compaction + patch table, [2] RefineNet INCLUDING the patch
- * gather (its conv1a reads the 24x24 windows out of the frames since round 3), [3] total.  */
+ * [0] detector conv stack, [1] fused tail (1x1 heads + arg-max + ordered compaction into the corner pool), [2] RefineNet INCLUDING
+ * the patch gather (its conv1a reads the 24x24 windows out of the frames since round 3), [3] total.  */
 int dcx_set_timing(int enabled);
 int dcx_get_timing(void);            /* 1 while per-stage timing is on (callers that capture hipGraphs must launch eagerly then) */
 int dcx_last_timings(float* h_ms4);

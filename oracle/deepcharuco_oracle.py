@@ -205,6 +205,23 @@ def infer_image(img_bgr: np.ndarray, dust_bin_ids: int, sd_dc: TensorDict,
     return np.array([[k[0], k[1], idx] for k, idx in sorted(zip(kpts, ids_np), key=lambda t: t[1])])
 
 
+def keypoint_confidences(loc_hat: torch.Tensor, ids_hat: torch.Tensor, dust_bin_ids: int) -> torch.Tensor:
+    """Confidences of the key-points ``pred_to_keypoints`` returns, in ITS order (torch.nonzero's raster order): (K,2) float32
+    [softmax(loc)[arg-max], softmax(ids)[arg-max]] per firing cell.
+
+    The reference's ``pred_to_keypoints`` (models/model_utils.py:81-88) promises "optionally confidences" in its docstring but
+    returns none, and nothing in the reference thresholds on a score; its heads are trained with cross-entropy on exactly these
+    logits (models/net.py:136-137), so the probability CE assigns -- ``torch.softmax(logits, dim=1)`` at the arg-max class -- is
+    the only confidence the reference's own arithmetic defines.  This is that expression in stock torch on the reference's
+    logits; there is no reference output to pin it to beyond the logits themselves (which ARE pinned, make_golden.py)."""
+    assert loc_hat.ndim == 4 and ids_hat.ndim == 4
+    loc_argmax, ids_argmax = pred_argmax(loc_hat, ids_hat, dust_bin_ids)
+    mask = ids_argmax != dust_bin_ids
+    p_loc = torch.softmax(loc_hat, dim=1).max(dim=1).values
+    p_ids = torch.softmax(ids_hat, dim=1).max(dim=1).values
+    return torch.stack([p_loc[mask], p_ids[mask]], dim=1)
+
+
 def top2_margin(logits: torch.Tensor) -> torch.Tensor:
     """Per-position gap between the largest and second-largest channel (near-tie policy, H1)."""
     top = torch.topk(logits, 2, dim=1).values

@@ -633,8 +633,8 @@ def test_config5_bs32_1280x960_fixed_k16(dev):
     frames, kept = WL.select_fixed_k_frames("board4", 20000, 32, 960, 1280, 16, dc, dev)
     assert frames.shape == (32, 960, 1280) and len(set(kept)) == 32
     d = torch.from_numpy(frames).to(dev)
-    packed = infer_batch_device(d, 16, dc, rn, kmax=16).cpu().numpy()
-    res, counts = unpack_results(packed, 32, 16, True)
+    packed = infer_batch_device(d, 16, dc, rn, kmax=16).cpu().numpy()          # pool = 32 * 16: exactly what the batch fires
+    res, counts = unpack_results(packed, 32, 32 * 16, True)
     assert counts.tolist() == [16] * 32                                   # fixed K: every frame fires exactly 16 cells
     assert all(r.shape == (16, 3) and r.dtype == np.float64 for r in res)
     t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
@@ -643,7 +643,7 @@ def test_config5_bs32_1280x960_fixed_k16(dev):
         exp = O.infer_image(None, 16, t_dc, t_rn, gray=frames[b])
         assert res[b].shape == exp.shape and np.array_equal(res[b], exp), f"frame {b}"
         corners += exp.shape[0]
-    again = unpack_results(infer_batch_device(d, 16, dc, rn, kmax=16).cpu().numpy(), 32, 16, True)[0]
+    again = unpack_results(infer_batch_device(d, 16, dc, rn, kmax=16).cpu().numpy(), 32, 32 * 16, True)[0]
     assert all(np.array_equal(a, b) for a, b in zip(res, again))
     _report("config5_bs32_1280x960", dict(frames=32, corners_per_frame=16, frames_checked=4, corners_checked=corners,
                                           candidates_drawn=int(max(kept)) + 1))
@@ -678,13 +678,19 @@ def test_argument_validation_python_layer(dev, golden_tiny):
     with pytest.raises(ValueError):
         infer_batch_device(fr, 16, dc, rn, kmax=8, out=torch.empty(5, dtype=torch.int32, device=dev))
     with pytest.raises(ValueError):
-        infer_batch_device(fr, 16, dc, rn, kmax=8, out=torch.empty(1 + 8 * 6, dtype=torch.float32, device=dev))
+        infer_batch_device(fr, 16, dc, rn, kmax=8, out=torch.empty(2 + 8 * 6, dtype=torch.float32, device=dev))
     with pytest.raises(ValueError):
         infer_batch_device(fr, 16, dc, rn, kmax=8, ws=torch.empty(16, dtype=torch.uint8, device=dev))
     with pytest.raises(ValueError):
         infer_batch_device(fr.cpu(), 16, dc, rn, kmax=8)
-    out = torch.empty(1 + 8 * 6, dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError):
+        infer_batch_device(fr[0], 16, dc, rn, kmax=8)                  # (H,W): neither (B,H,W) gray nor (B,H,W,3) BGR
+    with pytest.raises(ValueError):
+        infer_batch_device(fr, 16, dc, rn, pool=0)
+    out = torch.empty(2 + 8 * 6, dtype=torch.int32, device=dev)       # counts[1] | starts[1] | rows[8][4] | xy[8][2]
     assert infer_batch_device(fr, 16, dc, rn, kmax=8, out=out).data_ptr() == out.data_ptr()
+    out = torch.empty(2 + 8 * 8, dtype=torch.int32, device=dev)       # ... | conf[8][2]
+    assert infer_batch_device(fr, 16, dc, rn, kmax=8, out=out, conf=True).data_ptr() == out.data_ptr()
     with pytest.raises(RuntimeError):
         dc.model.forward(torch.zeros((1, 1, 64, 96)))               # CPU tensor: no CPU path
     if torch.cuda.device_count() > 1:
@@ -712,8 +718,8 @@ def test_two_streams_share_one_model_pair(dev):
                 outs[i] = infer_batch_device(d[i * 8:(i + 1) * 8], 16, dc, rn, 64)
         torch.cuda.synchronize()
         for i in range(2):
-            a = unpack_results(outs[i].cpu().numpy(), 8, 64, True)[0]
-            b = unpack_results(ref[i], 8, 64, True)[0]
+            a = unpack_results(outs[i].cpu().numpy(), 8, 8 * 64, True)[0]
+            b = unpack_results(ref[i], 8, 8 * 64, True)[0]
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rep, i)
 
 
@@ -730,17 +736,17 @@ def test_hazard_soak_repeated_runs_are_bit_identical(dev):
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
     d = torch.from_numpy(frames).to(dev)
 
-    counts_all = unpack_results(infer_batch_device(d, 16, dc, rn, 64).cpu().numpy(), len(frames), 64, True)[1]
+    counts_all = unpack_results(infer_batch_device(d, 16, dc, rn, 64).cpu().numpy(), len(frames), len(frames) * 64, True)[1]
     busiest = int(np.argmax(counts_all))      # bs=1 soaks a frame that FIRES (round 3 soaked frame 0: no corners, RefineNet idle)
 
     def sha(b):
         lo = busiest if b == 1 else 0
         packed = infer_batch_device(d[lo:lo + b], 16, dc, rn, 64).cpu().numpy()
-        res, counts = unpack_results(packed, b, 64, True)
+        res, counts = unpack_results(packed, b, b * 64, True)         # (the frames' ORDER in the pool may differ run to run; their rows never)
         h = hashlib.sha256(counts.tobytes())
         for r in res:
             h.update(np.ascontiguousarray(r).tobytes())
-        return h.hexdigest(), int(np.minimum(counts, 64).sum())
+        return h.hexdigest(), int(counts.sum())
     report = {}
     for b, reps in ((32, 60), (1, 20), (7, 20), (64, 20)):
         first, corners = sha(b)
@@ -823,7 +829,7 @@ def test_hipgraph_replay_equals_eager_launches(dev, golden_tiny):
     sd0["convDb.bias"][16] = np.float32(1e4)
     kp, _ = I.infer_image(imgs[0], 16, lModel(dcModel(16, sd0, dev)), rn, device="cuda")
     assert kp.shape == (0,) and kp.dtype == np.float64
-    # capacity overflow inside a graphed call: exact eager re-run
+    # the batch fires more cells than the captured corner pool (2 frames x kmax 2 = 4 slots) holds: exact eager re-run
     gp = GraphedPipeline(16, dc, rn, batch=2, height=64, width=96, kmax=2, bgr=True)
     with pytest.warns(UserWarning):
         res = gp.run(np.stack([imgs[0], imgs[1]]))
@@ -1220,32 +1226,34 @@ def test_pitched_frame_buffer_through_c_abi(dev, golden_tiny):
     from deepcharuco_amd.models.refinenet import RefineNet
     L = _lib.lib()
     det, rf = dcModel(16, golden_tiny.sd_dc, dev), RefineNet(golden_tiny.sd_rn, dev)
-    h, w, b, kmax = 64, 96, 3, 32
+    h, w, b, pool = 64, 96, 3, 96
     frames = W.synthetic_frames("noise", 5, b, h, w)          # frame 0 is the golden frame (seed 5)
     pitch, fstride = 128, 128 * 70                             # padded rows, padded frames
     big = torch.full((b * fstride + 64,), 255, dtype=torch.uint8, device=dev)
     for i in range(b):
         view = big[17 + i * fstride: 17 + i * fstride + h * pitch].view(h, pitch)
         view[:, :w] = torch.from_numpy(frames[i]).to(dev)
-    nbytes = L.dcx_pipeline_workspace_bytes(det.handle, rf.handle, b, h, w, kmax)
+    nbytes = L.dcx_pipeline_workspace_bytes(det.handle, rf.handle, b, h, w, pool)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
     def run(ptr, stride, pit):
         counts = torch.zeros(b, dtype=torch.int32, device=dev)
-        rows = torch.zeros((b, kmax, 4), dtype=torch.int32, device=dev)
-        xy = torch.zeros((b, kmax, 2), dtype=torch.float32, device=dev)
-        _lib.check(L.dcx_infer_batch(det.handle, rf.handle, ptr, stride, pit, b, h, w, 16, kmax, ws.data_ptr(),
-                                     ws.numel(), counts.data_ptr(), rows.data_ptr(), xy.data_ptr(), None), "infer")
+        starts = torch.zeros(b, dtype=torch.int32, device=dev)
+        rows = torch.zeros((pool, 4), dtype=torch.int32, device=dev)
+        xy = torch.zeros((pool, 2), dtype=torch.float32, device=dev)
+        _lib.check(L.dcx_infer_batch(det.handle, rf.handle, ptr, stride, pit, 0, b, h, w, 16, pool, ws.data_ptr(),
+                                     ws.numel(), counts.data_ptr(), starts.data_ptr(), rows.data_ptr(), xy.data_ptr(), None, None), "infer")
         torch.cuda.synchronize()
-        return counts.cpu(), rows.cpu(), xy.cpu()
+        c, s_ = counts.cpu(), starts.cpu()
+        # frame i's corners are the pool slots [starts[i], starts[i] + counts[i])
+        return c, [rows.cpu()[int(s_[i]):int(s_[i]) + int(c[i])] for i in range(b)], [xy.cpu()[int(s_[i]):int(s_[i]) + int(c[i])] for i in range(b)]
     dense = torch.from_numpy(frames).to(dev)
     c0, r0, x0 = run(dense.data_ptr(), h * w, w)
     c1, r1, x1 = run(big.data_ptr() + 17, fstride, pitch)
-    assert torch.equal(c0, c1) and int(c0[0]) == golden_tiny.fx["kpts"].shape[0]
+    assert torch.equal(c0, c1) and int(c0[0]) == golden_tiny.fx["kpts"].shape[0] and int(c0.sum()) <= pool
     for i in range(b):
-        k = int(c0[i])
-        assert torch.equal(r0[i, :k], r1[i, :k]) and torch.equal(x0[i, :k], x1[i, :k])
-    assert np.array_equal(r0[0, :int(c0[0]), :2].numpy(), golden_tiny.fx["kpts"])
+        assert torch.equal(r0[i], r1[i]) and torch.equal(x0[i], x1[i])
+    assert np.array_equal(r0[0][:, :2].numpy(), golden_tiny.fx["kpts"])
 
 
 @pytest.mark.parametrize("hw", [(88, 104), (136, 200), (8, 8), (24, 1024), (248, 328), (250, 330), (243, 325), (67, 101), (9, 15), (100, 75)])
@@ -1296,3 +1304,222 @@ def test_reference_demo_resolution_2560x1920(dev):
     exp = O.infer_image(None, 16, O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn), gray=frame[0])
     assert exp.shape[0] >= 30
     assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+# --------------------------------------------------------------------------- round 5: corner pool, confidences, BGR batches
+
+def _oracle_margins(sd, frames, n_ids=16):
+    """Per cell: the oracle's fire margin (best id logit - dust-bin logit; -inf where loc says "no corner")."""
+    t = O.to_torch_state_dict(sd)
+    x = torch.from_numpy(np.stack([O.pre_bgr_image(f) for f in frames]))
+    loc, ids = O.detector_forward(t, x)
+    m = ids[:, :n_ids].max(1).values - ids[:, n_ids]
+    return torch.where(loc.argmax(1) == 64, torch.tensor(-1e30), m).reshape(len(frames), -1).numpy()
+
+
+def _busy_frame_weights(seed, frames, pool, busy_at_least=100):
+    """Seeded weights whose dust-bin bias is set (with the oracle) so that the batch fits `pool` corners in total while ONE frame
+    fires at least `busy_at_least` cells: the largest total <= pool whose threshold sits in a gap of >= 1e-4 between margins."""
+    sd = W.synthetic_state_dict("detector", seed, 16)
+    m = _oracle_margins(sd, frames)
+    flat = np.sort(m.ravel())[::-1]
+    for total in range(min(pool, flat.size - 1), 0, -1):
+        if flat[total - 1] - flat[total] < 1e-4 or flat[total] < -1e29:
+            continue
+        thr = (flat[total - 1] + flat[total]) / 2
+        per = (m > thr).sum(1)
+        if per.max() >= busy_at_least:
+            sd["convDb.bias"][16] += np.float32(thr)
+            return sd, per
+        break
+    pytest.skip(f"no threshold gives a >= {busy_at_least}-corner frame inside a pool of {pool} for these frames")
+
+
+def test_busy_frame_inside_a_kmax64_sized_batch(dev):
+    """the reference refines EVERY firing cell (inference.py:51-57, no cap).  A batch sized for 64 corners per
+    frame ON AVERAGE (pool = B x 64) with one frame firing 100+ cells and quiet frames beside it: ONE pass (no warning, no
+    re-run), every corner of every frame identical to the oracle; the same through FrameStream and a GraphedPipeline."""
+    import warnings
+    from deepcharuco_amd.graph import GraphedPipeline
+    from deepcharuco_amd.inference import infer_batch, infer_batch_device, unpack_results
+    from deepcharuco_amd.stream import FrameStream
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = np.concatenate([W.synthetic_frames("noise", 4100, 1, 240, 320), W.synthetic_frames("board", 4200, 5, 240, 320),
+                             np.zeros((1, 240, 320), np.uint8), W.synthetic_frames("board4", 4300, 1, 240, 320)])
+    B = len(frames)
+    sd_dc, per = _busy_frame_weights(4000, frames, pool=B * 64)
+    sd_rn = W.synthetic_state_dict("refinenet", 4001)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    exp = [O.infer_image(None, 16, t_dc, t_rn, gray=f) for f in frames]
+    ks = [0 if e.ndim == 1 else e.shape[0] for e in exp]
+    assert max(ks) >= 100 and sum(ks) <= B * 64, ks
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # a re-run would warn
+        got = infer_batch(frames, 16, dc, rn, kmax=64)
+    assert all(g.shape == e.shape and np.array_equal(g, e) for g, e in zip(got, exp))
+    # the packed pool itself: counts are exact, the frames' slot ranges are disjoint and inside the pool
+    packed = infer_batch_device(torch.from_numpy(frames).to(dev), 16, dc, rn, kmax=64).cpu().numpy()
+    res, counts = unpack_results(packed, B, B * 64, True)
+    starts = packed[B:2 * B]
+    assert counts.tolist() == ks and all(r is not None for r in res)
+    spans = sorted((int(s_), int(s_ + c)) for s_, c in zip(starts, counts) if c)
+    assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == sum(ks)
+    # FrameStream (pool = batch x kmax) and a two-frame graph whose pool is smaller than the busy frame alone would need per frame
+    fs = FrameStream(16, dc, rn, batch=4, height=240, width=320, kmax=64, depth=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = [a for _, r in fs.run([frames[:4], frames[4:]]) for a in r]
+    assert all(g.shape == e.shape and np.array_equal(g, e) for g, e in zip(out, exp))
+    busy = int(np.argmax(ks))
+    quiet = int(np.argmin(ks))
+    km = (ks[busy] + ks[quiet] + 1) // 2 + 1                  # the PAIR fits 2 x km slots; the busy frame alone is far above km
+    assert ks[busy] > km
+    gp = GraphedPipeline(16, dc, rn, batch=2, height=240, width=320, kmax=km, bgr=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        r2 = gp.run(frames[[busy, quiet]])
+    assert np.array_equal(r2[0], exp[busy]) and r2[1].shape == exp[quiet].shape and np.array_equal(r2[1], exp[quiet])
+    _report("busy_frame_in_kmax64_batch", dict(corners_per_frame=ks, pool=B * 64, passes=1))
+
+
+def test_pool_overflow_reruns_with_the_reported_size(dev):
+    """When the WHOLE batch fires more cells than the pool holds, infer_batch runs once more with a pool of exactly the size the
+    first pass reported (a warning says so) and returns complete lists; counts never depend on the pool."""
+    from deepcharuco_amd.inference import infer_batch, infer_batch_device
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 4400, 6, 120, 160)
+    sd_dc = _calibrated(4401, frames, target_per_frame=20)
+    sd_rn = W.synthetic_state_dict("refinenet", 4402)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    full = infer_batch(frames, 16, dc, rn, kmax=64)
+    total = sum(r.shape[0] for r in full if r.ndim == 2)
+    assert total > 60
+    d = torch.from_numpy(frames).to(dev)
+    c_big = infer_batch_device(d, 16, dc, rn, pool=6 * 64)[:6].cpu().numpy()
+    for pool in (1, 7, total - 1):
+        assert np.array_equal(infer_batch_device(d, 16, dc, rn, pool=pool)[:6].cpu().numpy(), c_big)
+        with pytest.warns(UserWarning, match=f"pool={total}"):
+            again = infer_batch(frames, 16, dc, rn, pool=pool)
+        assert all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(again, full))
+    exact = infer_batch(frames, 16, dc, rn, pool=total)          # fits exactly: no warning, one pass
+    assert all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(exact, full))
+
+
+@pytest.mark.parametrize("name", ["noise_240x320", "diverse_ids_240x320", "tiny_noise_64x96"])
+def test_confidences_are_the_softmax_of_the_reference_logits(dev, name):
+    """Optional confidence output of the fused tail (north-star: "loc/ids 65-/17-way softmax ... fused"; the reference's
+    pred_to_keypoints docstring, model_utils.py:81-84, mentions confidences).  Oracle: torch.softmax over the logits THE REFERENCE
+    produced (committed in the fixture), taken at the arg-max class of every firing cell.  Tolerance 1e-5 (a probability; the
+    logits agree to 1.4e-5 and d p / d logit <= 1/4).  The default outputs do not change when confidences are requested."""
+    from conftest import GoldenCase
+    from deepcharuco_amd.inference import infer_batch
+    case = GoldenCase(name)
+    dc, rn = _models(case, dev)
+    loc = torch.from_numpy(case.fx["loc_logits"])[None]
+    ids = torch.from_numpy(case.fx["ids_logits"])[None]
+    exp_c = O.keypoint_confidences(loc, ids, case.n_ids).numpy()
+    order = np.argsort(case.fx["ids_found"], kind="stable")       # infer_image's order: by id, stable
+    exp_c = exp_c[order]
+    res, confs = infer_batch(case.frame[None], case.n_ids, dc, rn, conf=True)
+    plain = infer_batch(case.frame[None], case.n_ids, dc, rn)
+    assert np.array_equal(res[0], case.fx["final_rn"]) and np.array_equal(plain[0], res[0])
+    assert confs[0].shape == exp_c.shape and confs[0].dtype == np.float32
+    err = float(np.abs(confs[0] - exp_c).max())
+    assert err <= 1e-5, err
+    assert np.all(confs[0] > 1.0 / 65 - 1e-6) and np.all(confs[0] <= 1.0 + 1e-6)
+    # live oracle too (its logits are the container's torch build on the same weights), batch of the frame repeated
+    t_dc = O.to_torch_state_dict(case.sd_dc)
+    l2, i2 = O.detector_forward(t_dc, torch.from_numpy(O.pre_bgr_image(case.frame))[None])
+    exp2 = O.keypoint_confidences(l2, i2, case.n_ids).numpy()[order]
+    _, confs3 = infer_batch(np.repeat(case.frame[None], 3, 0), case.n_ids, dc, None, conf=True)
+    assert all(np.abs(c - exp2).max() <= 1e-5 for c in confs3)
+    _report(f"confidence/{name}", dict(corners=int(exp_c.shape[0]), max_abs_err=err,
+                                        p_loc_range=[float(exp_c[:, 0].min()), float(exp_c[:, 0].max())],
+                                        p_ids_range=[float(exp_c[:, 1].min()), float(exp_c[:, 1].max())]))
+
+
+def test_confidences_with_more_than_32_ids(dev):
+    """n_ids = 40: the ids head spans two 32-row MFMA tiles, whose partial soft-max sums are re-based on the common maximum."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.models.net import dcModel, lModel
+    frames = W.synthetic_frames("board", 4500, 3, 120, 160)
+    sd_dc = _calibrated(4501, frames, n_ids=40, target_per_frame=15)
+    dc = lModel(dcModel(40, sd_dc, dev))
+    t_dc = O.to_torch_state_dict(sd_dc)
+    res, confs = infer_batch(frames, 40, dc, None, conf=True)
+    n = 0
+    for b in range(3):
+        l, i = O.detector_forward(t_dc, torch.from_numpy(O.pre_bgr_image(frames[b]))[None])
+        kp, idf = O.pred_to_keypoints(l, i, 40)
+        exp = O.keypoint_confidences(l, i, 40).numpy()[np.argsort(idf.numpy(), kind="stable")]
+        assert confs[b].shape == exp.shape and np.abs(confs[b] - exp).max() <= 1e-5
+        n += exp.shape[0]
+    assert n >= 30
+
+
+def test_batched_bgr_entry(dev):
+    """the reference's callers hold BGR frames (pose_estimation.py:53-59, benchmark.py:37-41).  infer_batch and
+    FrameStream take (B,H,W,3) uint8; the cv2.cvtColor of inference.py:40 happens inside the first layer's load (and inside
+    RefineNet's patch gather).  Colour frames that contain the committed pixels on which the 15-bit (OpenCV 4.x) and 14-bit
+    constants DISAGREE, both variants, vs the oracle fed with the oracle's gray image of the same variant."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.stream import FrameStream
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    rng = np.random.default_rng(4600)
+    gray = np.concatenate([W.synthetic_frames("board", 4600, 3, 120, 160), W.synthetic_frames("noise", 4601, 2, 120, 160)]).astype(np.int16)
+    bgr = np.clip(np.stack([gray + rng.integers(-40, 41, gray.shape), gray + rng.integers(-8, 9, gray.shape),
+                            gray + rng.integers(-40, 41, gray.shape)], axis=-1), 0, 255).astype(np.uint8)
+    d = np.load(os.path.join(REPO, "tests", "golden", "bgr2gray_formula.npz"))
+    bgr[:, 40:56, 64:96] = d["bgr_differ"]                    # 512 pixels per frame where the variants differ, inside the image
+    g15 = np.stack([O.bgr2gray(f, "opencv4") for f in bgr])
+    g14 = np.stack([O.bgr2gray(f, "legacy14") for f in bgr])
+    assert int((g15 != g14).sum()) >= 5 * 512
+    sd_dc = _calibrated(4602, g15, target_per_frame=14)
+    sd_rn = W.synthetic_state_dict("refinenet", 4603)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+    n = 0
+    for variant, g in (("opencv4", g15), ("legacy14", g14)):
+        exp = [O.infer_image(None, 16, t_dc, t_rn, gray=f) for f in g]
+        got = infer_batch(bgr, 16, dc, rn, bgr_variant=variant)                       # host array
+        got_d = infer_batch(torch.from_numpy(bgr).to(dev), 16, dc, rn, bgr_variant=variant)     # GPU tensor
+        got_g = infer_batch(g, 16, dc, rn)                                            # the gray path on the converted frames
+        for a, b_, c, e in zip(got, got_d, got_g, exp):
+            assert a.shape == e.shape and a.dtype == e.dtype and np.array_equal(a, e)
+            assert np.array_equal(a, b_) and np.array_equal(a, c)
+        n += sum(e.shape[0] for e in exp if e.ndim == 2)
+    assert n > 60
+    exp = [O.infer_image(None, 16, t_dc, t_rn, gray=f) for f in g15]
+    fs = FrameStream(16, dc, rn, batch=2, height=120, width=160, kmax=64, depth=2, bgr=True)
+    out = [a for _, r in fs.run([bgr[0:2], bgr[2:4], bgr[4:5]]) for a in r]
+    assert len(out) == 5 and all(a.shape == e.shape and np.array_equal(a, e) for a, e in zip(out, exp))
+    with pytest.raises(ValueError):
+        fs.submit(g15[:2])                                    # a gray batch into a BGR stream
+    with pytest.raises(ValueError):
+        infer_batch(bgr, 16, dc, rn, bgr_variant="opencv2")
+
+
+def test_inference_model_wrapper(dev, golden_tiny, tmp_path):
+    """The north-star's ``InferenceModel`` (both nets + device behind the reference's call shapes) end to end from checkpoint
+    files: infer_image == the committed reference output ``final_rn``; infer_batch on gray and on BGR frames; confidences."""
+    from conftest import GoldenCase
+    from deepcharuco_amd.inference import InferenceModel
+    p1, p2 = str(tmp_path / "dc.ckpt"), str(tmp_path / "rn.ckpt")
+    W.save_lightning_style_checkpoint(p1, golden_tiny.sd_dc)
+    W.save_lightning_style_checkpoint(p2, golden_tiny.sd_rn)
+    m = InferenceModel(p1, p2, n_ids=16, device="cuda")
+    kp, img = m.infer_image(golden_tiny.bgr)
+    assert img is golden_tiny.bgr and kp.dtype == np.float64 and np.array_equal(kp, golden_tiny.fx["final_rn"])
+    for _ in range(3):                                        # replays of the cached hipGraph
+        assert np.array_equal(m.infer_image(golden_tiny.bgr)[0], golden_tiny.fx["final_rn"])
+    res = m.infer_batch(np.stack([golden_tiny.frame] * 3))
+    assert len(res) == 3 and all(np.array_equal(r, golden_tiny.fx["final_rn"]) for r in res)
+    res_bgr, confs = m.infer_batch(np.stack([golden_tiny.bgr] * 2), conf=True)
+    assert all(np.array_equal(r, golden_tiny.fx["final_rn"]) for r in res_bgr) and confs[0].shape == (kp.shape[0], 2)
+    m2 = InferenceModel(p1, None, n_ids=16, device="cuda")   # detector only: int64 rows (inference.py:54)
+    kp2, _ = m2.infer_image(golden_tiny.bgr)
+    assert m2.refinenet is None and kp2.dtype == np.int64 and np.array_equal(kp2, golden_tiny.fx["final_norn"])

@@ -106,21 +106,29 @@ def test_synthetic_frames_are_per_frame_deterministic():
 
 
 def test_unpack_results_sorting_and_dtypes():
-    from deepcharuco_amd.inference import unpack_results
-    b, kmax = 3, 4
-    packed = np.zeros(b + b * kmax * 4 + b * kmax * 2, np.int32)
-    packed[:b] = [3, 0, 9]   # frame 2 overflows kmax
-    rows = packed[b:b + b * kmax * 4].reshape(b, kmax, 4)
-    rows[0, :3] = [[8, 9, 5, 1], [16, 17, 2, 2], [24, 25, 5, 3]]
-    rows[2, :4] = [[1, 1, 0, 0], [2, 2, 0, 1], [3, 3, 0, 2], [4, 4, 0, 3]]
-    xy = packed[b + b * kmax * 4:].view(np.float32).reshape(b, kmax, 2)
-    xy[0, :3] = [[8.5, 9.25], [16.125, 17], [24, 25.5]]
-    res, counts = unpack_results(packed, b, kmax, True)
+    """The packed corner pool: counts[B] | starts[B] | rows[pool][4] | xy[pool][2] (| conf[pool][2]); frames sit in the pool in any
+    order (starts[]), a frame may own any share of it, a frame that does not fit completely comes back as None."""
+    from deepcharuco_amd.inference import packed_len, unpack_results
+    b, pool = 4, 8
+    assert packed_len(b, pool) == 2 * b + 6 * pool and packed_len(b, pool, True) == 2 * b + 8 * pool
+    packed = np.zeros(packed_len(b, pool, True), np.int32)
+    packed[:b] = [3, 0, 4, 5]                 # 12 corners > pool: the frame that was placed last does not fit
+    packed[b:2 * b] = [4, 7, 0, 7]            # frame 2 came first, then frame 0, then frame 3 (slots 7..11: only one exists)
+    rows = packed[2 * b:2 * b + 4 * pool].reshape(pool, 4)
+    rows[4:7] = [[8, 9, 5, 1], [16, 17, 2, 2], [24, 25, 5, 3]]
+    rows[0:4] = [[1, 1, 0, 0], [2, 2, 0, 1], [3, 3, 0, 2], [4, 4, 0, 3]]
+    xy = packed[2 * b + 4 * pool:2 * b + 6 * pool].view(np.float32).reshape(pool, 2)
+    xy[4:7] = [[8.5, 9.25], [16.125, 17], [24, 25.5]]
+    cf = packed[2 * b + 6 * pool:].view(np.float32).reshape(pool, 2)
+    cf[4:7] = [[0.5, 0.25], [0.75, 0.125], [1.0, 0.0625]]
+    res, counts, confs = unpack_results(packed, b, pool, True, conf=True)
     assert res[0].dtype == np.float64
     assert np.array_equal(res[0], [[16.125, 17, 2], [8.5, 9.25, 5], [24, 25.5, 5]])   # stable by id
-    assert res[1].shape == (0,) and res[1].dtype == np.float64
-    assert res[2].shape == (4, 3) and counts.tolist() == [3, 0, 9]
-    res, _ = unpack_results(packed, b, kmax, False)
+    assert np.array_equal(confs[0], [[0.75, 0.125], [0.5, 0.25], [1.0, 0.0625]]) and confs[0].dtype == np.float32
+    assert res[1].shape == (0,) and res[1].dtype == np.float64 and confs[1].shape == (0, 2)
+    assert res[2].shape == (4, 3) and counts.tolist() == [3, 0, 4, 5]
+    assert res[3] is None and confs[3] is None and int(counts.sum()) > pool            # the caller re-runs with pool >= 12
+    res, _ = unpack_results(packed[:packed_len(b, pool)], b, pool, False)
     assert res[0].dtype == np.int64 and np.array_equal(res[0], [[16, 17, 2], [8, 9, 5], [24, 25, 5]])
 
 
@@ -401,6 +409,9 @@ def test_graph_cache_clear_is_reentrant():
     class Pipe:
         def __init__(self, ref):
             self.ref = ref
+
+        def close(self):             # GraphedPipeline.close(): retire (lock-free); the buffers die under the device locks
+            pass
 
         def __del__(self):
             G.drop_graphs_of_refiner(self.ref)

@@ -9,7 +9,7 @@ from deepcharuco_amd import weights as W, workload as WL
 from deepcharuco_amd.inference import infer_batch_device
 from deepcharuco_amd.models.net import dcModel, lModel
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
-from deepcharuco_amd.sharding import packed_len
+from deepcharuco_amd.inference import packed_len
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29519")
 dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -17,7 +17,7 @@ B, kmax = 32, 64
 frames = torch.from_numpy(W.synthetic_frames("board", 1000, B, 240, 320)).to(dev)
 sd = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), frames, dev)
 dc, rn = lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
-n = packed_len(B, kmax)
+n = packed_len(B, B * kmax)
 side = torch.cuda.Stream()
 out = [torch.empty((n,), dtype=torch.int32, device=dev) for _ in range(2)]
 gath = [torch.empty((n,), dtype=torch.int32, device=dev) for _ in range(2)]
