@@ -551,6 +551,9 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* f
         rc = dcx_launch_conv_mfma(a, 3, 0, DCX_EPI_HEAT, s);
         if (rc) return rc;
     }
+    // (finalising inside the head kernel -- per-patch tickets, the last work item reduces -- was built and measured in round 5: the
+    //  device-scope fence ahead of the ticket drains the item's software pipeline, 0.359 -> 0.693 ms at bs=32;
+    //  profiles/experiments/r05_fused_finalize.md)
     return dcx_launch_refine_finalize((const float*)(ws + L.pval), (const int*)(ws + L.pidx), heat_tiles, 64, p, lim,
                                       d_table, d_corners, d_xy, s);
 }

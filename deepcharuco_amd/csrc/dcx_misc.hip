@@ -43,7 +43,10 @@ struct DcxPixF32 {
 // One thread = one output pixel, all 64 output channels; acc = fmaf(w[tap], x[tap], acc) for
 // tap = 0..8 (dy-major), then +bias, BN affine, ReLU.  Write-bound: 256 B per pixel, C4 layout,
 // 16-B stores contiguous across lanes.
-template <typename PX>
+// CS = channel split: 1 -> a thread computes all 64 output channels of its pixel (big batches: the kernel is HBM-write bound);
+// 4 -> blockIdx.z picks 16 of them (one frame: 1,200 waves of 1,000 instructions each leave the chip latency-bound -- four times
+// as many waves, each a quarter as long: 13.6 -> ~6 us at 320x240, bs=1).  Same arithmetic per output, same bits.
+template <typename PX, int CS>
 __global__ __launch_bounds__(256) void dcx_conv1_kernel(const uint8_t* __restrict__ in, long image_stride, int pitch,
                                                           int h, int w, int pad,
                                                           const float* __restrict__ w9x64,
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const uint8_t* __restric
                                                           const int* __restrict__ n_limit, int n_images,
                                                           int32_t* __restrict__ zero_words, int n_zero) {
     __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
-    if (zero_words != nullptr && blockIdx.x == 0 && blockIdx.y == 0)      // image_stride / pitch are in BYTES
+    if (zero_words != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)      // image_stride / pitch are in BYTES
         for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0;
     int n_end = n_images;
     if (n_limit != nullptr) n_end = min(n_end, *n_limit);
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const uint8_t* __restric
         }
     float4* out4 = reinterpret_cast<float4*>(out);
     const float4* sw4 = reinterpret_cast<const float4*>(sw);
+    const int cq_lo = CS == 1 ? 0 : (int)blockIdx.z * (16 / CS);
 #pragma unroll 4
-    for (int cq = 0; cq < 16; ++cq) {
+    for (int cq = cq_lo; cq < cq_lo + 16 / CS; ++cq) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -205,9 +209,15 @@ static int launch_conv1(const uint8_t* in, long image_stride, int pitch, int n, 
     if (!in || !w9x64 || !bias || !alpha || !beta || !out) return DCX_E_ARG;
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
     if (ho <= 0 || wo <= 0 || n <= 0) return DCX_E_SHAPE;
-    dim3 grid((unsigned)((ho * wo + 255) / 256), (unsigned)(n < 65535 ? n : 65535));
-    hipLaunchKernelGGL((dcx_conv1_kernel<PX>), grid, dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
-                       w9x64, bias, alpha, beta, out, ho, wo, n_limit, n, zero_words, n_zero);
+    const unsigned gx = (unsigned)((ho * wo + 255) / 256), gy = (unsigned)(n < 65535 ? n : 65535);
+    // few pixels in the launch (one or two 320x240 frames; n_limit launches are sized for their capacity and stay unsplit):
+    // split the 64 channels over four workgroups so that the chip has enough waves in flight
+    if (n_limit == nullptr && (long)gx * gy < 1024)
+        hipLaunchKernelGGL((dcx_conv1_kernel<PX, 4>), dim3(gx, gy, 4), dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
+                           w9x64, bias, alpha, beta, out, ho, wo, n_limit, n, zero_words, n_zero);
+    else
+        hipLaunchKernelGGL((dcx_conv1_kernel<PX, 1>), dim3(gx, gy), dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
+                           w9x64, bias, alpha, beta, out, ho, wo, n_limit, n, zero_words, n_zero);
     return (int)hipGetLastError();
 }
 

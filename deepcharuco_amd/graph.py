@@ -18,8 +18,10 @@ graphs are bypassed while per-stage timing / per-launch profiling is on (their h
 """
 from __future__ import annotations
 
+import os
 import threading
 import time
+import warnings
 import weakref
 from typing import List, Optional
 
@@ -27,7 +29,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, packed_len, unpack_results
+from .inference import DEFAULT_KMAX, PIXEL_FORMATS, infer_batch, launch_pipeline, packed_len, unpack_results
 
 
 class _DeviceLocks:
@@ -87,7 +89,7 @@ _locks = _DeviceLocks()
 
 class GraphedPipeline:
     def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 1, height: int = 240, width: int = 320,
-                 kmax: int = DEFAULT_KMAX, bgr: bool = True):
+                 kmax: int = DEFAULT_KMAX, bgr: bool = True, zero_copy: Optional[int] = None):
         det = deepc.model if hasattr(deepc, "model") else deepc
         ref = None if refinenet is None else (refinenet.model if hasattr(refinenet, "model") else refinenet)
         self.dev = det.device
@@ -98,6 +100,7 @@ class GraphedPipeline:
         self._det, self._ref = weakref.ref(det), (None if ref is None else weakref.ref(ref))
         self.batch, self.h, self.w, self.kmax, self.bgr = batch, height, width, kmax, bgr
         self.pool = batch * kmax
+        self.zero_copy = int(os.environ.get("DCX_GRAPH_ZEROCOPY", "2")) if zero_copy is None else int(zero_copy)
         self._lock = _locks.device(self.dev.index)
         self.graph = None
         L = _lib.lib()
@@ -142,10 +145,20 @@ class GraphedPipeline:
         return ref
 
     def _enqueue(self) -> None:
-        self.dev_in.copy_(self.pin_in, non_blocking=True)
-        # BGR frames: the conversion of inference.py:40 happens in the first layer's load (DCX_PIX_BGR8), no separate kernel
-        infer_batch_device(self.dev_in, self.dust_bin_ids, self.deepc, self.refinenet, out=self.out_dev, ws=self.ws, pool=self.pool)
-        self.pin_out.copy_(self.out_dev, non_blocking=True)
+        # BGR frames: the conversion of inference.py:40 happens in the first layer's load (DCX_PIX_BGR8), no separate kernel.
+        # zero_copy bit 0: the kernels read the frame straight out of the pinned host buffer (conv1a of both nets are the only
+        # readers: 77-230 KB over the host link instead of a copy node + a device read); bit 1: the tail / finalize kernels
+        # write the corner list straight into pinned host memory (1.6 KB) instead of a device buffer + a copy node.
+        det, ref = self.deepc, self.refinenet
+        bpp = 3 if self.bgr else 1
+        src = self.pin_in if self.zero_copy & 1 else self.dev_in
+        dst = self.pin_out if self.zero_copy & 2 else self.out_dev
+        if not self.zero_copy & 1:
+            self.dev_in.copy_(self.pin_in, non_blocking=True)
+        launch_pipeline(det, ref, src.data_ptr(), self.batch, self.h, self.w, bpp, PIXEL_FORMATS["opencv4" if self.bgr else "gray"],
+                        self.dust_bin_ids, self.pool, self.ws, dst.data_ptr())
+        if not self.zero_copy & 2:
+            self.pin_out.copy_(self.out_dev, non_blocking=True)
 
     def run(self, frames: np.ndarray) -> List[np.ndarray]:
         """frames: (B,H,W,3) BGR or (B,H,W) gray uint8 host array (as configured) -> list of B keypoint arrays."""
@@ -162,6 +175,7 @@ class GraphedPipeline:
             res, counts = unpack_results(out_np, self.batch, self.pool, self.refinenet is not None)
             need = int(counts.astype(np.int64).sum())
             if need > self.pool:                              # rare: more corners than the captured pool -> exact eager re-run
+                warnings.warn(f"the call produced {need} corners > the captured graph's pool={self.pool}; re-running eagerly with pool={need}")
                 res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need)
         return res
 

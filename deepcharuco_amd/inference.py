@@ -134,6 +134,19 @@ def packed_len(batch: int, pool: int, conf: bool = False) -> int:
     return 2 * batch + (8 if conf else 6) * pool
 
 
+def launch_pipeline(det, ref, frames_ptr: int, b: int, h: int, w: int, bpp: int, pix: int, dust_bin_ids: int, pool: int,
+                    ws: torch.Tensor, out_ptr: int, conf: bool = False) -> None:
+    """``dcx_infer_batch`` on raw pointers (current device / stream): dense frames at ``frames_ptr``, the packed result
+    (``packed_len(b, pool, conf)`` int32 words) at ``out_ptr``.  The pointers only have to be DEVICE-ACCESSIBLE: pinned host
+    memory qualifies, which is how the bs=1 hipGraph reads the frame and writes the corner list without copy nodes."""
+    counts_p, starts_p, rows_p = out_ptr, out_ptr + 4 * b, out_ptr + 8 * b
+    xy_p = rows_p + 16 * pool
+    conf_p = xy_p + 8 * pool
+    _lib.check(_lib.lib().dcx_infer_batch(det.handle, ref.handle if ref else None, frames_ptr, h * w * bpp, w * bpp, pix, b, h, w,
+                                          dust_bin_ids, pool, ws.data_ptr(), ws.numel(), counts_p, starts_p, rows_p,
+                                          xy_p if ref else None, conf_p if conf else None, _lib.current_stream()), "dcx_infer_batch")
+
+
 def infer_batch_device(frames: torch.Tensor, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DEFAULT_KMAX,
                        out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, pool: Optional[int] = None,
                        conf: bool = False, bgr_variant: str = "opencv4") -> torch.Tensor:
@@ -187,13 +200,7 @@ def infer_batch_device(frames: torch.Tensor, dust_bin_ids: int, deepc, refinenet
             out = torch.empty((n_i32,), dtype=torch.int32, device=dev)
         elif out.device != dev or out.dtype != torch.int32 or out.numel() != n_i32 or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous int32 tensor of {n_i32} elements on {dev}")
-        base = out.data_ptr()
-        counts_p, starts_p, rows_p = base, base + 4 * b, base + 8 * b
-        xy_p = rows_p + 16 * pool
-        conf_p = xy_p + 8 * pool
-        _lib.check(L.dcx_infer_batch(det.handle, ref.handle if ref else None, frames.data_ptr(), h * w * bpp, w * bpp, pix, b, h, w,
-                                     dust_bin_ids, pool, ws.data_ptr(), ws.numel(), counts_p, starts_p, rows_p,
-                                     xy_p if ref else None, conf_p if conf else None, _lib.current_stream()), "dcx_infer_batch")
+        launch_pipeline(det, ref, frames.data_ptr(), b, h, w, bpp, pix, dust_bin_ids, pool, ws, out.data_ptr(), conf)
     return out
 
 

@@ -12,6 +12,7 @@ the next batches; ``run`` then yields ``(ticket, results, poses)``.
 """
 from __future__ import annotations
 
+import warnings
 from typing import Iterable, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -63,6 +64,7 @@ class FrameStream:
         res = res[:n]
         need = int(counts.astype(np.int64).sum())
         if need > self.pool:         # rare: the batch fired more cells than its pool holds -> exact re-run with the pool it asked for
+            warnings.warn(f"a batch produced {need} corners > pool={self.pool} (batch x kmax); re-running it with pool={need}")
             res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need)
         if self.pnp is not None:     # host stage: futures now, resolved when the batch is handed out
             return ticket, res, solve_pnp_submit(res, **self.pnp)

@@ -74,6 +74,10 @@ def main():
         n_rag = n - 3                                                    # 1,021 at world 8: 128 x5 + 127 x3
         rag = local_batch("board", SEED + 9000, n_rag, h, w, rank, world)
         (res_r,) = list(infer_batches_sharded([rag], 16, dc, rn, kmax=kmax))
+        # every rank's pool far too small (128 frames x 2 slots): all ranks see it in the gathered counts and repeat the batch
+        # collectively with the pool the first pass reported -- complete results, no exception
+        (res_small,) = list(infer_batches_sharded([rag], 16, dc, rn, kmax=2))
+        rerun_same = len(res_small) == len(res_r) and all(same(a, b) for a, b in zip(res_small, res_r))
         if rank == 0:
             from oracle import deepcharuco_oracle as O
             t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
@@ -99,6 +103,12 @@ def main():
                 per_rank.append(int(nbad))
                 bad += nbad
             counts = [0 if a.ndim == 1 else a.shape[0] for a in res_a]
+            busiest = int(np.argmax(counts))                  # no per-frame cap: the frame with the most corners, wherever it lives
+            e = ora(SEED, busiest)
+            bad += not same(res_a[busiest], e)
+            verdict.update(busiest_frame=dict(index=busiest, corners=int(counts[busiest]), identical=bool(same(res_a[busiest], e)),
+                                              frames_over_64=int(sum(c > 64 for c in counts))),
+                           pool_per_rank=128 * kmax, overflow_rerun_identical=bool(rerun_same))
             verdict.update(frames=n, frames_ragged=n_rag, split=[shard_range(n, r, world) for r in range(world)],
                            split_ragged=[shard_range(n_rag, r, world) for r in range(world)],
                            results_returned=[len(res_a), len(res_b), len(res_r)], frames_checked=checked, corners_checked=corners,

@@ -1207,7 +1207,8 @@ def test_bench_script_emits_parity_block_and_exit_code(dev):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["parity"]["frames_checked"] == 3 and d["parity"]["mismatched_frames"] == 0 and d["parity"]["corners"] > 0
+    # 3 frames + the busiest frame of the timed batch
+    assert d["parity"]["frames_checked"] in (3, 4) and d["parity"]["mismatched_frames"] == 0 and d["parity"]["corners"] > 0
     assert "BASELINE configs[1]" in d["config"]["workload"] and d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma"
     out = subprocess.run(cmd + ["--batch", "5", "--height", "120", "--width", "160"], env=env, capture_output=True, text=True, timeout=600)
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
@@ -1367,10 +1368,10 @@ def test_busy_frame_inside_a_kmax64_sized_batch(dev):
     spans = sorted((int(s_), int(s_ + c)) for s_, c in zip(starts, counts) if c)
     assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == sum(ks)
     # FrameStream (pool = batch x kmax) and a two-frame graph whose pool is smaller than the busy frame alone would need per frame
-    fs = FrameStream(16, dc, rn, batch=4, height=240, width=320, kmax=64, depth=2)
+    fs = FrameStream(16, dc, rn, batch=B, height=240, width=320, kmax=64, depth=2)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        out = [a for _, r in fs.run([frames[:4], frames[4:]]) for a in r]
+        out = [a for _, r in fs.run([frames, frames[4:6]]) for a in r][:B]       # (+ a short batch: its blank padding frames fire too)
     assert all(g.shape == e.shape and np.array_equal(g, e) for g, e in zip(out, exp))
     busy = int(np.argmax(ks))
     quiet = int(np.argmin(ks))
@@ -1455,7 +1456,7 @@ def test_confidences_with_more_than_32_ids(dev):
         l, i = O.detector_forward(t_dc, torch.from_numpy(O.pre_bgr_image(frames[b]))[None])
         kp, idf = O.pred_to_keypoints(l, i, 40)
         exp = O.keypoint_confidences(l, i, 40).numpy()[np.argsort(idf.numpy(), kind="stable")]
-        assert confs[b].shape == exp.shape and np.abs(confs[b] - exp).max() <= 1e-5
+        assert confs[b].shape == exp.shape and (exp.size == 0 or np.abs(confs[b] - exp).max() <= 1e-5)
         n += exp.shape[0]
     assert n >= 30
 
@@ -1512,14 +1513,15 @@ def test_inference_model_wrapper(dev, golden_tiny, tmp_path):
     W.save_lightning_style_checkpoint(p1, golden_tiny.sd_dc)
     W.save_lightning_style_checkpoint(p2, golden_tiny.sd_rn)
     m = InferenceModel(p1, p2, n_ids=16, device="cuda")
-    kp, img = m.infer_image(golden_tiny.bgr)
-    assert img is golden_tiny.bgr and kp.dtype == np.float64 and np.array_equal(kp, golden_tiny.fx["final_rn"])
+    bgr = golden_tiny.bgr
+    kp, img = m.infer_image(bgr)
+    assert img is bgr and kp.dtype == np.float64 and np.array_equal(kp, golden_tiny.fx["final_rn"])
     for _ in range(3):                                        # replays of the cached hipGraph
-        assert np.array_equal(m.infer_image(golden_tiny.bgr)[0], golden_tiny.fx["final_rn"])
+        assert np.array_equal(m.infer_image(bgr)[0], golden_tiny.fx["final_rn"])
     res = m.infer_batch(np.stack([golden_tiny.frame] * 3))
     assert len(res) == 3 and all(np.array_equal(r, golden_tiny.fx["final_rn"]) for r in res)
-    res_bgr, confs = m.infer_batch(np.stack([golden_tiny.bgr] * 2), conf=True)
+    res_bgr, confs = m.infer_batch(np.stack([bgr] * 2), conf=True)
     assert all(np.array_equal(r, golden_tiny.fx["final_rn"]) for r in res_bgr) and confs[0].shape == (kp.shape[0], 2)
     m2 = InferenceModel(p1, None, n_ids=16, device="cuda")   # detector only: int64 rows (inference.py:54)
-    kp2, _ = m2.infer_image(golden_tiny.bgr)
+    kp2, _ = m2.infer_image(bgr)
     assert m2.refinenet is None and kp2.dtype == np.int64 and np.array_equal(kp2, golden_tiny.fx["final_norn"])

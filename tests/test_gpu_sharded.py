@@ -69,6 +69,10 @@ def test_world8_cfg4_full_size_every_rank_checked(tmp_path):
     assert [b - a for a, b in v["split_ragged"]] == [128] * 5 + [127] * 3
     assert v["mismatched"] == 0 and v["mismatched_per_rank"] == [0] * 8 and v["frames_checked"] >= 8 * 10
     assert v["corners_checked"] > 500
+    # round 5: the pool is sized for 64 corners per frame on average and has no per-frame cap: the busiest of the 1,024 frames
+    # (some fire more than 64 cells) is complete and identical to the oracle; pools that are far too small are repeated collectively
+    assert v["pool_per_rank"] == 128 * 64 and v["busiest_frame"]["identical"] and v["busiest_frame"]["corners"] == v["max_corners"]
+    assert v["overflow_rerun_identical"]
 
 
 def test_world8_cfg5_reduced_every_rank_checked(tmp_path):

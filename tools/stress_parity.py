@@ -7,6 +7,16 @@ corners the oracle finds (every 4th frame), and every 4th frame is also compared
 The largest |HIP logit - oracle logit| is recorded per resolution: the arg-max policy of tests/test_gpu_parity.py (MARGIN)
 must be >= 2x that number, and this table is the evidence that nothing disagrees above it.
 
+Round 5 -- FOUR comparisons against the same oracle pass (batched, N threads), bucketed by ITS top-2 margins:
+  hip_default   the product path (Winograd families)                     -- what ships
+  hip_direct    the product path in deterministic mode (direct family: every multiply-add of the layers as written)
+                                                                          -- what Winograd costs in parity is (hip_default - hip_direct)
+  oracle_1thr   the SAME oracle code on the SAME tensors with torch.set_num_threads(1)
+                                                                          -- the reference's own noise floor between thread counts
+  oracle_bs1    the oracle one frame per call (the reference's real protocol, inference.py:32-70) vs the batched pass, same threads
+                                                                          -- the reference's own noise floor between batch sizes
+"statistical parity" is defensible exactly as far as hip_default is at or below the oracle_* columns.
+
 The oracle side (frame rendering, torch-CPU detector / RefineNet) runs in worker processes; the main process owns the GPU and
 compares on the device.      usage (MI355X):   python tools/stress_parity.py [frames=20000] [workers=14] [threads=16]
 Writes gpurun_out/stress_parity_summary.json (copy to profiles/) and prints the table."""
@@ -77,11 +87,34 @@ def oracle_chunk(spec):
         kp_all.append(kp.numpy()); fr_idx.append(np.full(kp.shape[0], b)); heat_idx.append(top.indices[:, 0].numpy())
         heat_margin.append((top.values[:, 0] - top.values[:, 1]).numpy())
     cat = lambda l, dt: np.concatenate(l).astype(dt) if l else np.zeros((0,), dt)
+    kp_cat = np.concatenate(kp_all).astype(np.int64) if kp_all else np.zeros((0, 2), np.int64)
+    kf_cat = cat(fr_idx, np.int64)
+
+    def heat_argmax_on(kp_np, kf_np):
+        """flat arg-max of the oracle's heat-maps on GIVEN key-points (the N-thread pass's), under the current thread count"""
+        out = []
+        for b in np.unique(kf_np):
+            k = torch.from_numpy(kp_np[kf_np == b])
+            heat = O.refinenet_forward(t_rn, O.extract_patches(x[int(b)], k)[:, None])[:, 0].reshape(k.shape[0], -1)
+            out.append(heat.argmax(1).numpy())
+        return cat(out, np.int64)
+
+    # ---- the reference against ITSELF (1): one frame per call, same thread count (inference.py:32-70 is per frame) -- every 4th frame
+    loc_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[0] for b in sub])
+    ids_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[1] for b in sub])
+    # ---- the reference against ITSELF (2): the same tensors, one thread
+    torch.set_num_threads(1)
+    loc_1t, ids_1t = O.detector_forward(t_dc, x)
+    heat_idx_1t = heat_argmax_on(kp_cat, kf_cat) if kp_cat.shape[0] else np.zeros((0,), np.int64)
+    finals_1t = [O.infer_image(None, N_IDS, t_dc, t_rn, gray=frames[b]) for b in sub]
+    torch.set_num_threads(threads)
     path = os.path.join(SHM, f"dcx_stress_{os.getpid()}_{cid}.npz")
     np.savez(path, frames=frames, loc=loc.numpy(), ids=ids.numpy(), convDb_bias=sd_dc["convDb.bias"].astype(np.float32),
-             kp=np.concatenate(kp_all).astype(np.int64) if kp_all else np.zeros((0, 2), np.int64), kp_frame=cat(fr_idx, np.int64),
+             kp=kp_cat, kp_frame=kf_cat,
              heat_idx=cat(heat_idx, np.int64), heat_margin=cat(heat_margin, np.float32), sub=np.array(sub),
-             finals=np.array(finals, dtype=object), wseed=wseed, cid=cid)
+             finals=np.array(finals, dtype=object), wseed=wseed, cid=cid,
+             loc_1t=loc_1t.numpy(), ids_1t=ids_1t.numpy(), heat_idx_1t=heat_idx_1t, finals_1t=np.array(finals_1t, dtype=object),
+             loc_b1=loc_b1.numpy(), ids_b1=ids_b1.numpy())
     return path
 
 
@@ -101,15 +134,56 @@ def main():
     from deepcharuco_amd.models.model_utils import extract_patches, pre_bgr_image
     from deepcharuco_amd.models.net import dcModel, lModel
     from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    from deepcharuco_amd.inference import set_deterministic
     dev = torch.device("cuda", 0)
     edges = torch.tensor(EDGES[1:-1], device=dev)
     nb = len(EDGES) - 1
     zero = lambda: {"cells": np.zeros(nb, np.int64), "disagree": np.zeros(nb, np.int64)}
-    stats = {"loc": zero(), "ids": zero(), "heat": zero(), "fire": zero()}
+    COLS = ("hip_default", "hip_direct", "oracle_1thr", "oracle_bs1")
+    col = {c: {"stats": {"loc": zero(), "ids": zero(), "heat": zero(), "fire": zero()}, "max_abs_logit_diff": 0.0, "sum_abs": 0.0,
+               "count": 0, "cells_decided_differently": 0, "e2e_frames": 0, "e2e_bad": 0, "e2e_corners": 0, "frames": 0} for c in COLS}
     ids_hist = np.zeros(N_IDS, np.int64)
     per_res = {}
-    frames_done = e2e_frames = e2e_bad = corners = cells_decided_differently = 0
+    frames_done = 0
     t0 = time.time()
+
+    def compare_logits(c, g_loc, g_ids, o_loc, o_ids):
+        """one column: candidate logits (g_*) against the N-thread batched oracle's (o_*), bucketed by the ORACLE's margins"""
+        C = col[c]
+        C["frames"] += g_loc.shape[0]
+        for name, g, o in (("loc", g_loc, o_loc), ("ids", g_ids, o_ids)):
+            diff = (g - o).abs()
+            C["max_abs_logit_diff"] = max(C["max_abs_logit_diff"], float(diff.max()))
+            C["sum_abs"] += float(diff.sum()); C["count"] += diff.numel()
+            top = torch.topk(o, 2, dim=1).values
+            bucket = torch.bucketize((top[:, 0] - top[:, 1]).flatten(), edges, right=True)
+            bad = (g.argmax(1) != o.argmax(1)).flatten()
+            C["stats"][name]["cells"] += torch.bincount(bucket, minlength=nb).cpu().numpy()
+            C["stats"][name]["disagree"] += torch.bincount(bucket[bad], minlength=nb).cpu().numpy()
+        # the decision the reference takes per cell: (fires?, id, 8x8 offset)
+        o_la, o_ia, g_la, g_ia = o_loc.argmax(1), o_ids.argmax(1), g_loc.argmax(1), g_ids.argmax(1)
+        fire_o, fire_g = (o_la != 64) & (o_ia != N_IDS), (g_la != 64) & (g_ia != N_IDS)
+        C["cells_decided_differently"] += int(((fire_o != fire_g) | (fire_o & ((o_la != g_la) | (o_ia != g_ia)))).sum())
+        # fire / no-fire by the distance of the oracle's decision from its threshold (cells whose loc head fires)
+        fm = (o_ids[:, :N_IDS].max(1).values - o_ids[:, N_IDS]).abs()[o_la != 64]
+        bucket = torch.bucketize(fm, edges, right=True)
+        C["stats"]["fire"]["cells"] += torch.bincount(bucket, minlength=nb).cpu().numpy()
+        C["stats"]["fire"]["disagree"] += torch.bincount(bucket[(fire_o != fire_g)[o_la != 64]], minlength=nb).cpu().numpy()
+        return fire_o, o_ia
+
+    def compare_heat(c, idx, z):
+        bucket = np.digitize(z["heat_margin"], EDGES[1:-1], right=False)
+        col[c]["stats"]["heat"]["cells"] += np.bincount(bucket, minlength=nb)
+        col[c]["stats"]["heat"]["disagree"] += np.bincount(bucket[idx != z["heat_idx"]], minlength=nb)
+
+    def compare_e2e(c, res, finals):
+        for a, e in zip(res, finals):
+            e = np.asarray(e, dtype=np.float64) if np.asarray(e).size else np.array([])
+            a = np.asarray(a, dtype=np.float64) if np.asarray(a).size else np.array([])
+            col[c]["e2e_frames"] += 1
+            col[c]["e2e_corners"] += 0 if e.ndim == 1 else e.shape[0]
+            col[c]["e2e_bad"] += not (a.shape == e.shape and np.array_equal(a, e))
+
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
         for path in pool.imap_unordered(oracle_chunk, specs):
@@ -122,76 +196,69 @@ def main():
             sd_rn = W.synthetic_state_dict("refinenet", int(z["wseed"]) + 1)
             det, ref = dcModel(N_IDS, sd_dc, dev), RefineNet(sd_rn, dev)
             d_frames = torch.from_numpy(frames).to(dev)
-            got = det.forward_u8(d_frames)
             o_loc, o_ids = torch.from_numpy(z["loc"]).to(dev), torch.from_numpy(z["ids"]).to(dev)
-            r = per_res.setdefault(f"{w}x{h}", {"frames": 0, "max_abs_logit_diff": 0.0, "sum_abs": 0.0, "count": 0})
+            r = per_res.setdefault(f"{w}x{h}", {"frames": 0})
             r["frames"] += n
-            for name, g, o in (("loc", got["loc"], o_loc), ("ids", got["ids"], o_ids)):
-                diff = (g - o).abs()
-                r["max_abs_logit_diff"] = max(r["max_abs_logit_diff"], float(diff.max()))
-                r["sum_abs"] += float(diff.sum()); r["count"] += diff.numel()
-                top = torch.topk(o, 2, dim=1).values
-                bucket = torch.bucketize((top[:, 0] - top[:, 1]).flatten(), edges, right=True)
-                bad = (g.argmax(1) != o.argmax(1)).flatten()
-                stats[name]["cells"] += torch.bincount(bucket, minlength=nb).cpu().numpy()
-                stats[name]["disagree"] += torch.bincount(bucket[bad], minlength=nb).cpu().numpy()
-            # the decision the reference takes per cell: (fires?, id, 8x8 offset)
-            o_la, o_ia, g_la, g_ia = o_loc.argmax(1), o_ids.argmax(1), got["loc"].argmax(1), got["ids"].argmax(1)
-            fire_o, fire_g = (o_la != 64) & (o_ia != N_IDS), (g_la != 64) & (g_ia != N_IDS)
-            cells_decided_differently += int(((fire_o != fire_g) | (fire_o & ((o_la != g_la) | (o_ia != g_ia)))).sum())
-            # fire / no-fire by the distance of the oracle's decision from its threshold (cells whose loc head fires)
-            fm = (o_ids[:, :N_IDS].max(1).values - o_ids[:, N_IDS]).abs()[o_la != 64]
-            bucket = torch.bucketize(fm, edges, right=True)
-            stats["fire"]["cells"] += torch.bincount(bucket, minlength=nb).cpu().numpy()
-            stats["fire"]["disagree"] += torch.bincount(bucket[(fire_o != fire_g)[o_la != 64]], minlength=nb).cpu().numpy()
-            ids_hist += torch.bincount(o_ia[fire_o], minlength=N_IDS + 1)[:N_IDS].cpu().numpy()
-            # RefineNet on the oracle's key-points (every 4th frame)
-            kp, kf = z["kp"], z["kp_frame"]
+            kp, kf, sub = z["kp"], z["kp_frame"], z["sub"]
+            patches = None
             if kp.shape[0]:
-                xs = torch.stack([torch.from_numpy(pre_bgr_image(frames[b])) for b in z["sub"]]).to(dev)       # (S,1,h,w)
-                pos = {int(b): i for i, b in enumerate(z["sub"])}
+                xs = torch.stack([torch.from_numpy(pre_bgr_image(frames[b])) for b in sub]).to(dev)       # (S,1,h,w)
+                pos = {int(b): i for i, b in enumerate(sub)}
                 patches = torch.cat([extract_patches(xs[pos[int(b)]], torch.from_numpy(kp[kf == b]).to(dev)) for b in np.unique(kf)])
-                _, cor = ref.infer_patches(patches, torch.from_numpy(kp).to(dev))
-                idx = (cor[:, 1] * 64 + cor[:, 0]).cpu().numpy()
-                bucket = np.digitize(z["heat_margin"], EDGES[1:-1], right=False)
-                stats["heat"]["cells"] += np.bincount(bucket, minlength=nb)
-                stats["heat"]["disagree"] += np.bincount(bucket[idx != z["heat_idx"]], minlength=nb)
-            # end to end (every 4th frame)
-            res = infer_batch(frames[z["sub"]], N_IDS, lModel(det), lRefineNet(ref), kmax=128)
-            for a, e in zip(res, z["finals"]):
-                e = np.asarray(e, dtype=np.float64) if np.asarray(e).size else np.array([])
-                e2e_frames += 1
-                corners += 0 if e.ndim == 1 else e.shape[0]
-                e2e_bad += not (a.shape == e.shape and np.array_equal(a, e))
+            for c, direct in (("hip_default", False), ("hip_direct", True)):
+                set_deterministic(direct)
+                got = det.forward_u8(d_frames)
+                fire_o, o_ia = compare_logits(c, got["loc"], got["ids"], o_loc, o_ids)
+                if c == "hip_default":
+                    ids_hist += torch.bincount(o_ia[fire_o], minlength=N_IDS + 1)[:N_IDS].cpu().numpy()
+                if patches is not None:          # RefineNet on the oracle's key-points (every 4th frame)
+                    _, cor = ref.infer_patches(patches, torch.from_numpy(kp).to(dev))
+                    compare_heat(c, (cor[:, 1] * 64 + cor[:, 0]).cpu().numpy(), z)
+                compare_e2e(c, infer_batch(frames[sub], N_IDS, lModel(det), lRefineNet(ref), kmax=128), z["finals"])     # end to end (every 4th frame)
+            set_deterministic(False)
+            # the reference against itself: one thread; one frame per call
+            compare_logits("oracle_1thr", torch.from_numpy(z["loc_1t"]).to(dev), torch.from_numpy(z["ids_1t"]).to(dev), o_loc, o_ids)
+            if kp.shape[0]:
+                compare_heat("oracle_1thr", z["heat_idx_1t"], z)
+            compare_e2e("oracle_1thr", z["finals_1t"], z["finals"])
+            si = torch.from_numpy(np.asarray(sub)).to(dev)
+            compare_logits("oracle_bs1", torch.from_numpy(z["loc_b1"]).to(dev), torch.from_numpy(z["ids_b1"]).to(dev), o_loc[si], o_ids[si])
             frames_done += n
-            print(f"[{time.time() - t0:6.0f}s] {frames_done:6d} frames  ({w}x{h} x{n})  loc disagreements {int(stats['loc']['disagree'].sum())}  "
-                  f"ids {int(stats['ids']['disagree'].sum())}  heat {int(stats['heat']['disagree'].sum())}  e2e bad frames {e2e_bad}/{e2e_frames}", flush=True)
+            print(f"[{time.time() - t0:6.0f}s] {frames_done:6d} frames  ({w}x{h} x{n})  arg-max disagreements (loc+ids / heat / e2e frames):  " +
+                  "  ".join(f"{c} {int(col[c]['stats']['loc']['disagree'].sum() + col[c]['stats']['ids']['disagree'].sum())}/"
+                            f"{int(col[c]['stats']['heat']['disagree'].sum())}/{col[c]['e2e_bad']}" for c in COLS), flush=True)
             del det, ref
-    for r in per_res.values():
-        r["mean_abs_logit_diff"] = r.pop("sum_abs") / max(1, r.pop("count"))
     label = [f"[{EDGES[i]:g}, {EDGES[i + 1]:g})" for i in range(nb)]
-    out = {"frames": frames_done, "seconds": round(time.time() - t0, 1), "per_resolution": per_res,
-           "max_abs_logit_diff": max(r["max_abs_logit_diff"] for r in per_res.values()),
-           "cells_whose_decision_differs": cells_decided_differently,
+    for C in col.values():
+        C["mean_abs_logit_diff"] = C.pop("sum_abs") / max(1, C.pop("count"))
+        C["histogram"] = {k: {"decided": v["cells"].tolist(), "differs": v["disagree"].tolist()} for k, v in C.pop("stats").items()}
+        C["end_to_end"] = {"frames": C.pop("e2e_frames"), "corners": C.pop("e2e_corners"), "mismatched_frames": C.pop("e2e_bad")}
+    out = {"frames": frames_done, "seconds": round(time.time() - t0, 1), "per_resolution": per_res, "oracle_threads": threads,
+           "reference_pass": f"oracle, all frames of a chunk in one batch, {threads} threads",
+           "columns": {"hip_default": "product path (Winograd families) vs the reference pass",
+                       "hip_direct": "product path, deterministic mode (direct family) vs the reference pass",
+                       "oracle_1thr": "the oracle itself with torch.set_num_threads(1) vs the reference pass",
+                       "oracle_bs1": "the oracle one frame per call (every 4th frame; logits only) vs the reference pass"},
            "firing_cells_per_id": ids_hist.tolist(),
            "weight_sets": "61 seeds; a third of the chunks with the ids-head biases equalised per class (all 16 ids fire); every second chunk "
                           "with the dust-bin threshold within +-2e-4 of a cell's own margin (fire/no-fire sampled where it is close)",
-           "end_to_end": {"frames": e2e_frames, "corners": corners, "mismatched_frames": e2e_bad},
-           "buckets": label,
-           "histogram": {k: {"decided": v["cells"].tolist(), "hip_disagrees": v["disagree"].tolist()} for k, v in stats.items()}}
+           "buckets": label, "results": col}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "stress_parity_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print(f"\n{frames_done} frames, max |HIP - oracle| logit {out['max_abs_logit_diff']:.3e}; "
-          f"cells decided differently: {cells_decided_differently}; end to end: {e2e_bad} of {e2e_frames} frames differ ({corners} corners)")
+    print(f"\n{frames_done} frames; reference pass = oracle batched at {threads} threads; every column is compared with IT")
     print("firing cells per id:", ids_hist.tolist())
-    print(f"{'|fire margin| (ids max - dust-bin)':>36s} | {'cells':>12s} {'fire/no-fire differs':>22s}")
-    for i in range(nb):
-        print(f"{label[i]:>36s} | {stats['fire']['cells'][i]:12d} {stats['fire']['disagree'][i]:22d}")
-    print(f"{'oracle top-2 margin':>22s} | {'loc cells':>12s} {'differ':>7s} | {'ids cells':>12s} {'differ':>7s} | {'heat-maps':>10s} {'differ':>7s}")
-    for i in range(nb):
-        print(f"{label[i]:>22s} | {stats['loc']['cells'][i]:12d} {stats['loc']['disagree'][i]:7d} | {stats['ids']['cells'][i]:12d} "
-              f"{stats['ids']['disagree'][i]:7d} | {stats['heat']['cells'][i]:10d} {stats['heat']['disagree'][i]:7d}")
+    print(f"{'':24s}" + "".join(f"{c:>16s}" for c in COLS))
+    print(f"{'max |logit diff|':24s}" + "".join(f"{col[c]['max_abs_logit_diff']:16.3e}" for c in COLS))
+    print(f"{'mean |logit diff|':24s}" + "".join(f"{col[c]['mean_abs_logit_diff']:16.3e}" for c in COLS))
+    print(f"{'cells decided differently':24s}" + "".join(f"{col[c]['cells_decided_differently']:16d}" for c in COLS))
+    print(f"{'e2e frames differing':24s}" + "".join(f"{str(col[c]['end_to_end']['mismatched_frames']) + '/' + str(col[c]['end_to_end']['frames']):>16s}" for c in COLS))
+    for name, title in (("loc", "loc 65-way arg-max"), ("ids", "ids 17-way arg-max"), ("heat", "RefineNet 4096-way arg-max"), ("fire", "fire / no-fire (by |ids max - dust-bin|)")):
+        print(f"\n{title}: decided by the reference pass | differs in column")
+        print(f"{'oracle margin':>22s} | {'decided':>12s} |" + "".join(f"{c:>14s}" for c in COLS))
+        for i in range(nb):
+            print(f"{label[i]:>22s} | {col['hip_default']['histogram'][name]['decided'][i]:12d} |" +
+                  "".join(f"{col[c]['histogram'][name]['differs'][i]:14d}" for c in COLS))
 
 
 if __name__ == "__main__":
