@@ -39,6 +39,11 @@ constexpr int kTailPF = 2;   // prefetch distance in k-steps (measured at bs=32 
 // Ordered compaction of ONE frame's packed codes into the batch's corner pool; all 256 threads of the workgroup call it.
 // Super-chunks of 2,048 cells: eight coalesced loads per thread in flight at once, wave ballots, per-(chunk, wave) counts through
 // LDS -- one L2 round trip and two barriers for a 320x240 frame (1,200 cells).
+// The codes (and per-cell confidences) were stored write-through by work items on any XCD: they are read with agent-scope (sc1) loads.
+__device__ __forceinline__ int dcx_ld_agent(const int32_t* p) {
+    return __hip_atomic_load(const_cast<int32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool CONF>
 __device__ __forceinline__ void dcx_tail_compact_frame(const int32_t* codes, int cells, int dust_bin, int b, const DcxPoolOut& po,
                                                        int* s_cnt /*[32]*/, int* s_bcast) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,7 +53,7 @@ __device__ __forceinline__ void dcx_tail_compact_frame(const int32_t* codes, int
     int total = 0;
     if (nsuper > 1) {                                // big frames: the frame's count first (the pool slots are reserved before any row is written)
         int c = 0;
-        for (int i = tid; i < cells; i += 256) c += ((fc[i] >> 8) != dust_bin) ? 1 : 0;
+        for (int i = tid; i < cells; i += 256) c += ((dcx_ld_agent(fc + i) >> 8) != dust_bin) ? 1 : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
         if (lane == 0) s_cnt[wave] = c;
@@ -62,7 +67,7 @@ __device__ __forceinline__ void dcx_tail_compact_frame(const int32_t* codes, int
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int cell = sc * 2048 + c * 256 + tid;
-            code[c] = cell < cells ? fc[cell] : idle;
+            code[c] = cell < cells ? dcx_ld_agent(fc + cell) : idle;
         }
         unsigned long long m[8];
 #pragma unroll
@@ -101,7 +106,11 @@ __device__ __forceinline__ void dcx_tail_compact_frame(const int32_t* codes, int
                     const int y = 8 * cy + (la >> 3);             // ys = 8*iy + loc // 8   (model_utils.py:122)
                     reinterpret_cast<int4*>(po.rows)[pos] = make_int4(x, y, ia, cell);
                     if (po.table) reinterpret_cast<int4*>(po.table)[pos] = make_int4(b, x, y, pos);
-                    if (po.conf) reinterpret_cast<float2*>(po.conf)[pos] = reinterpret_cast<const float2*>(po.conf_cells)[(size_t)b * cells + cell];
+                    if (CONF && po.conf) {
+                        const unsigned long long cv = __hip_atomic_load(reinterpret_cast<unsigned long long*>(po.conf_cells) + (size_t)b * cells + cell,
+                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        reinterpret_cast<unsigned long long*>(po.conf)[pos] = cv;
+                    }
                 }
             }
         }
@@ -246,24 +255,29 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
                     if (red_i[t][tid] != 0x7fffffff) sl += red_s[t][tid] * expf(red_v[t][tid] - lv);
                 si = red_s[3][tid] * expf(red_v[3][tid] - iv);
                 if (IDS_TILES > 1 && red_i[4][tid] != 0x7fffffff) si += red_s[4][tid] * expf(red_v[4][tid] - iv);
-                reinterpret_cast<float2*>(po.conf_cells)[o] = make_float2(1.0f / sl, 1.0f / si);
+                const float2 cf2 = make_float2(1.0f / sl, 1.0f / si);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(po.conf_cells) + o, *reinterpret_cast<const unsigned long long*>(&cf2),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (la == 64) ia = dust_bin;         // where(loc_argmax == 64, dust_bin, ids_argmax)  model_utils.py:76
-            codes[o] = la | (ia << 8);
+            // write-through (sc1) store: the frame's last work item -- possibly on another XCD, whose L2 is not coherent with this
+            // one -- reads the code without anybody paying for a release fence (MI355X_MICROARCH.md, inter-workgroup visibility)
+            __hip_atomic_store(codes + o, la | (ia << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (loc_argmax) loc_argmax[o] = la;
             if (ids_argmax) ids_argmax[o] = ia;
         }
     }
     if (po.tickets == nullptr) return;
-    // ---- the frame's last work item compacts the frame ("last block": every thread publishes its codes with a device-scope
-    //      fence, one thread draws the ticket; the workgroup that draws the frame's last one sees all of them after its own fence)
-    __threadfence();
+    // ---- the frame's last work item compacts the frame.  Hand-off without fences: the codes were stored write-through, every
+    //      wave drains its stores, then ONE lane draws the frame's ticket (relaxed agent-scope atomic); the workgroup that draws the
+    //      last one reads the frame's codes with agent-scope (sc1) loads, which bypass its L1.  (Round 5's first version had every
+    //      thread of every work item run __threadfence() on both sides: 30 -> 136 us at bs=32.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&po.tickets[b], 1) == tiles_per_frame - 1;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&po.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles_per_frame - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    dcx_tail_compact_frame(codes, cells, dust_bin, b, po, s_cnt, &s_bcast);
+    dcx_tail_compact_frame<CONF>(codes, cells, dust_bin, b, po, s_cnt, &s_bcast);
 }
 
 }  // namespace

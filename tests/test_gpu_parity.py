@@ -1525,3 +1525,41 @@ def test_inference_model_wrapper(dev, golden_tiny, tmp_path):
     m2 = InferenceModel(p1, None, n_ids=16, device="cuda")   # detector only: int64 rows (inference.py:54)
     kp2, _ = m2.infer_image(bgr)
     assert m2.refinenet is None and kp2.dtype == np.int64 and np.array_equal(kp2, golden_tiny.fx["final_norn"])
+
+
+def test_tail_handoff_is_never_stale(dev):
+    """The detector tail hands its per-cell codes to the frame's last work item without fences (write-through stores, one ticket,
+    agent-scope loads; csrc/dcx_tail.hip) and the code buffer is reused by every call.  A stale read would return the PREVIOUS
+    call's code for a cell, which repeated runs on the same frames can never show -- so: three different batches (different
+    content in every frame slot, different corner counts) alternate through ONE workspace, 150 calls at bs=32 and 150 at bs=1,
+    with other work in flight on a second stream (uneven load), and every call's packed counts + rows + xy must equal what that
+    batch gives in a workspace of its own."""
+    from deepcharuco_amd.inference import infer_batch_device, unpack_results
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    batches = [W.synthetic_frames("board", 5100, 32, 240, 320), W.synthetic_frames("noise", 5200, 32, 240, 320),
+               np.ascontiguousarray(W.synthetic_frames("board", 5300, 32, 240, 320)[::-1])]
+    sd_dc = _calibrated(5101, np.concatenate([b[:3] for b in batches]), target_per_frame=16)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 5102), dev))
+    d = [torch.from_numpy(b).to(dev) for b in batches]
+
+    def canon(packed, b):
+        res, counts = unpack_results(packed.cpu().numpy(), b, b * 64, True)
+        return counts.tobytes() + b"".join(np.ascontiguousarray(r).tobytes() for r in res)
+    for bs in (32, 1):
+        want = []
+        for x in d:          # reference results: each batch in a fresh workspace
+            want.append(canon(infer_batch_device(x[:bs], 16, lModel(dcModel(16, sd_dc, dev)), rn, 64), bs))
+        assert len(set(want)) == 3                           # the batches really differ
+        side = torch.cuda.Stream()
+        noise = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        bad = 0
+        for i in range(150):
+            k = (i * 7 + i // 5) % 3
+            if i % 3 == 0:
+                with torch.cuda.stream(side):                # uneven load: a memory-bound kernel now and then beside the pipeline
+                    noise.add_(1)
+            got = canon(infer_batch_device(d[k][:bs], 16, dc, rn, 64), bs)
+            bad += got != want[k]
+        torch.cuda.synchronize()
+        assert bad == 0, f"bs={bs}: {bad} of 150 calls differ from the fresh-workspace result"

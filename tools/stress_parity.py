@@ -144,7 +144,7 @@ def main():
                "count": 0, "cells_decided_differently": 0, "e2e_frames": 0, "e2e_bad": 0, "e2e_corners": 0, "frames": 0} for c in COLS}
     ids_hist = np.zeros(N_IDS, np.int64)
     per_res = {}
-    frames_done = 0
+    frames_done = chunks_done = 0
     t0 = time.time()
 
     def compare_logits(c, g_loc, g_ids, o_loc, o_ids):
@@ -183,6 +183,31 @@ def main():
             col[c]["e2e_frames"] += 1
             col[c]["e2e_corners"] += 0 if e.ndim == 1 else e.shape[0]
             col[c]["e2e_bad"] += not (a.shape == e.shape and np.array_equal(a, e))
+
+    label = [f"[{EDGES[i]:g}, {EDGES[i + 1]:g})" for i in range(nb)]
+
+    def summarize():
+        """the JSON summary of what has been compared so far (also written every 25 chunks: a cut-off run keeps its evidence)"""
+        res = {}
+        for c, C in col.items():
+            res[c] = {"frames": C["frames"], "max_abs_logit_diff": C["max_abs_logit_diff"],
+                      "mean_abs_logit_diff": C["sum_abs"] / max(1, C["count"]), "cells_decided_differently": C["cells_decided_differently"],
+                      "histogram": {k: {"decided": v["cells"].tolist(), "differs": v["disagree"].tolist()} for k, v in C["stats"].items()},
+                      "end_to_end": {"frames": C["e2e_frames"], "corners": C["e2e_corners"], "mismatched_frames": C["e2e_bad"]}}
+        out = {"frames": frames_done, "seconds": round(time.time() - t0, 1), "per_resolution": per_res, "oracle_threads": threads,
+               "reference_pass": f"oracle, all frames of a chunk in one batch, {threads} threads",
+               "columns": {"hip_default": "product path (Winograd families) vs the reference pass",
+                           "hip_direct": "product path, deterministic mode (direct family) vs the reference pass",
+                           "oracle_1thr": "the oracle itself with torch.set_num_threads(1) vs the reference pass",
+                           "oracle_bs1": "the oracle one frame per call (every 4th frame; logits only) vs the reference pass"},
+               "firing_cells_per_id": ids_hist.tolist(),
+               "weight_sets": "61 seeds; a third of the chunks with the ids-head biases equalised per class (all 16 ids fire); every second chunk "
+                              "with the dust-bin threshold within +-2e-4 of a cell's own margin (fire/no-fire sampled where it is close)",
+               "buckets": label, "results": res}
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "stress_parity_summary.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        return out
 
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
@@ -228,24 +253,11 @@ def main():
                   "  ".join(f"{c} {int(col[c]['stats']['loc']['disagree'].sum() + col[c]['stats']['ids']['disagree'].sum())}/"
                             f"{int(col[c]['stats']['heat']['disagree'].sum())}/{col[c]['e2e_bad']}" for c in COLS), flush=True)
             del det, ref
-    label = [f"[{EDGES[i]:g}, {EDGES[i + 1]:g})" for i in range(nb)]
-    for C in col.values():
-        C["mean_abs_logit_diff"] = C.pop("sum_abs") / max(1, C.pop("count"))
-        C["histogram"] = {k: {"decided": v["cells"].tolist(), "differs": v["disagree"].tolist()} for k, v in C.pop("stats").items()}
-        C["end_to_end"] = {"frames": C.pop("e2e_frames"), "corners": C.pop("e2e_corners"), "mismatched_frames": C.pop("e2e_bad")}
-    out = {"frames": frames_done, "seconds": round(time.time() - t0, 1), "per_resolution": per_res, "oracle_threads": threads,
-           "reference_pass": f"oracle, all frames of a chunk in one batch, {threads} threads",
-           "columns": {"hip_default": "product path (Winograd families) vs the reference pass",
-                       "hip_direct": "product path, deterministic mode (direct family) vs the reference pass",
-                       "oracle_1thr": "the oracle itself with torch.set_num_threads(1) vs the reference pass",
-                       "oracle_bs1": "the oracle one frame per call (every 4th frame; logits only) vs the reference pass"},
-           "firing_cells_per_id": ids_hist.tolist(),
-           "weight_sets": "61 seeds; a third of the chunks with the ids-head biases equalised per class (all 16 ids fire); every second chunk "
-                          "with the dust-bin threshold within +-2e-4 of a cell's own margin (fire/no-fire sampled where it is close)",
-           "buckets": label, "results": col}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "stress_parity_summary.json"), "w") as f:
-        json.dump(out, f, indent=1)
+            chunks_done += 1
+            if chunks_done % 25 == 0:
+                summarize()
+    out = summarize()
+    col = out["results"]
     print(f"\n{frames_done} frames; reference pass = oracle batched at {threads} threads; every column is compared with IT")
     print("firing cells per id:", ids_hist.tolist())
     print(f"{'':24s}" + "".join(f"{c:>16s}" for c in COLS))
