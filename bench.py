@@ -590,7 +590,9 @@ def main():
         for n in todo:
             q = WL.PRESETS[n]
             st = 10 if q["height"] <= 240 else 5
-            r = run_config(cx, n, q["batch"], q["height"], q["width"], q["kmax"], q["frames"], q["fixed_k"], st, 3, False, 4)
+            # single GPU: every config carries its own roofline block (dominant kernel, per-kernel table, e2e executed fraction)
+            r = run_config(cx, n, q["batch"], q["height"], q["width"], q["kmax"], q["frames"], q["fixed_k"], st, 3,
+                           world == 1 and not args.no_profile, 4)
             if rank == 0:
                 r.pop("steps", None)
                 others[n] = r

@@ -428,7 +428,7 @@ int dcx_launch_compact(const int32_t* codes, int batch, int hc, int wc, int dust
                        int32_t* rows, hipStream_t s) {
     if (!codes || !counts || !rows) return DCX_E_ARG;
     if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0) return DCX_E_SHAPE;
-    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
+    if (dust_bin < 0 || dust_bin > 256) return DCX_E_NIDS;          // 256: "no label is the dust bin" (label maps only)
     hipLaunchKernelGGL(dcx_compact_kernel, dim3((unsigned)batch), dim3(256), 0, s, codes, hc, wc, dust_bin, kmax, counts, rows);
     return (int)hipGetLastError();
 }
@@ -460,7 +460,8 @@ extern "C" int dcx_label_to_keypoints(const long long* d_loc, const long long* d
                                       int kmax, int32_t* d_counts, int32_t* d_rows, int32_t* d_codes, int32_t* d_bad, void* stream) {
     if (!d_loc || !d_ids || !d_counts || !d_rows || !d_codes) return DCX_E_ARG;
     if (batch <= 0 || hc <= 0 || wc <= 0 || kmax <= 0) return DCX_E_SHAPE;
-    if (dust_bin < 0 || dust_bin > 255) return DCX_E_NIDS;
+    // a dust_bin outside [0, 255] equals no (8-bit) label: `ids != dust_bin_ids` (model_utils.py:111) is then true everywhere
+    if (dust_bin < 0 || dust_bin > 255) dust_bin = 256;
     const long n = (long)batch * hc * wc;
     hipLaunchKernelGGL(dcx_pack_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_loc, d_ids, n,
                        d_codes, d_bad);

@@ -29,12 +29,40 @@ DEFAULT_BGR2GRAY = "opencv4"
 
 
 def bgr2gray_variant_of_opencv(version: str) -> str:
-    """Which fixed-point variant a given ``cv2.__version__`` computes for 8-bit BGR->gray (4.x: 15-bit; before: 14-bit)."""
+    """Which fixed-point variant a given ``cv2.__version__`` computes for 8-bit BGR->gray, FROM THE VERSION STRING ALONE: only valid
+    for the range the reference pins (>= 4.6, < 4.12: 15-bit).  The constants did not change at the 3 -> 4 boundary -- the 15-bit
+    RGB2Gray landed mid-series (around 4.1.x, and was merged into late 3.4.x) -- so for any other version ask the installed module
+    itself: :func:`bgr2gray_variant_of_module`."""
     try:
         major = int(str(version).split(".")[0])
     except ValueError:
         return DEFAULT_BGR2GRAY
     return "opencv4" if major >= 4 else "legacy14"
+
+
+_PROBE = None
+
+
+def _probe_pixels() -> np.ndarray:
+    """A few BGR pixels on which the two fixed-point variants give different gray levels (found once, deterministically)."""
+    global _PROBE
+    if _PROBE is None:
+        g = np.arange(0, 256, 5, dtype=np.uint8)
+        cube = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(1, -1, 3)
+        dif = bgr2gray_fixed_point(cube, "opencv4") != bgr2gray_fixed_point(cube, "legacy14")
+        _PROBE = np.ascontiguousarray(cube[:, dif[0]][:, :16])
+    return _PROBE
+
+
+def bgr2gray_variant_of_module(cv2_module) -> str:
+    """Which variant the INSTALLED OpenCV computes: converts 16 pixels on which the variants differ and looks at the answer
+    (works for every version, unlike parsing ``cv2.__version__``).  Raises if it matches neither."""
+    px = _probe_pixels()
+    got = np.asarray(cv2_module.cvtColor(px, cv2_module.COLOR_BGR2GRAY))
+    for name in BGR2GRAY_VARIANTS:
+        if np.array_equal(got, bgr2gray_fixed_point(px, name)):
+            return name
+    raise RuntimeError("the installed OpenCV's 8-bit BGR->gray matches neither the 15-bit nor the 14-bit fixed-point formula")
 
 
 def bgr2gray_fixed_point(img_bgr: np.ndarray, variant: str = DEFAULT_BGR2GRAY) -> np.ndarray:

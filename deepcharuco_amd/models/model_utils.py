@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ._handles import check_dev_tensor
+from ._handles import check_dev_tensor, require_cuda
 
 
 def pre_bgr_image(image: np.ndarray) -> np.ndarray:
@@ -75,30 +75,37 @@ def pred_to_keypoints(loc_hat: torch.Tensor, ids_hat: torch.Tensor, dust_bin_ids
 def label_to_keypoints(loc: torch.Tensor, ids: torch.Tensor, dust_bin_ids: int):
     """model_utils.py:91-124: class-index maps (N,Hc,Wc) -- what ``pred_argmax`` returns, or a dataset label -- ->
     (kpts (K,2) int64 (x,y), ids (K,) int64) in ``torch.nonzero``'s raster order; ``mask = ids != dust_bin_ids``,
-    ``x = 8*ix + loc % 8``, ``y = 8*iy + loc // 8``.  Device tensors only (HIP: ``dcx_label_to_keypoints``)."""
+    ``x = 8*ix + loc % 8``, ``y = 8*iy + loc // 8`` (HIP: ``dcx_label_to_keypoints``).
+
+    Where this differs from the reference's function: the maps are processed on the GPU -- CPU tensors (the reference also runs
+    this on dataset labels, data.py) are moved to the current GPU and the result comes back on the CPU; class indices must lie in
+    [0, 255] (ValueError otherwise: they are packed into one word per cell; the reference's labels are < 65 / <= n_ids);
+    a ``dust_bin_ids`` outside [0, 255] can equal no label, so every cell fires, as ``ids != dust_bin_ids`` would say.
+    One host synchronisation (the dynamic output shape, as in the reference's ``torch.nonzero``)."""
     assert loc.ndim == 3 and ids.ndim == 3
-    dev = loc.device
-    if dev.type != "cuda" or ids.device != dev or loc.shape != ids.shape:
-        raise ValueError("label_to_keypoints expects two (N,Hc,Wc) label maps on the same GPU")
-    loc = loc.to(torch.int64).contiguous()
-    ids = ids.to(torch.int64).contiguous()
+    if ids.device != loc.device or loc.shape != ids.shape:
+        raise ValueError("label_to_keypoints expects two (N,Hc,Wc) label maps on the same device")
+    home = loc.device
+    dev = home if home.type == "cuda" else require_cuda("cuda")
+    loc = loc.to(device=dev, dtype=torch.int64).contiguous()
+    ids = ids.to(device=dev, dtype=torch.int64).contiguous()
     n, hc, wc = loc.shape
     kmax = hc * wc
-    counts = torch.empty((n,), dtype=torch.int32, device=dev)
+    meta = torch.zeros((n + 1,), dtype=torch.int32, device=dev)          # counts[n] | bad flag: one D2H
     rows = torch.empty((n, kmax, 4), dtype=torch.int32, device=dev)
     codes = torch.empty((n, kmax), dtype=torch.int32, device=dev)
-    bad = torch.zeros((1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().dcx_label_to_keypoints(loc.data_ptr(), ids.data_ptr(), n, hc, wc, dust_bin_ids, kmax, counts.data_ptr(),
-                                                     rows.data_ptr(), codes.data_ptr(), bad.data_ptr(), _lib.current_stream()),
+        _lib.check(_lib.lib().dcx_label_to_keypoints(loc.data_ptr(), ids.data_ptr(), n, hc, wc, int(dust_bin_ids), kmax, meta.data_ptr(),
+                                                     rows.data_ptr(), codes.data_ptr(), meta.data_ptr() + 4 * n, _lib.current_stream()),
                    "dcx_label_to_keypoints")
-    cnt = counts.cpu().tolist()
-    if int(bad.cpu()[0]):
+    m = meta.cpu().tolist()
+    cnt = m[:n]
+    if m[n]:
         raise ValueError("label_to_keypoints: class indices must lie in [0, 255]")
     parts = [rows[b, :c] for b, c in enumerate(cnt) if c > 0]
     if not parts:
-        return (torch.empty((0, 2), dtype=torch.int64, device=dev), torch.empty((0,), dtype=torch.int64, device=dev))
-    r = torch.cat(parts, dim=0).to(torch.int64)
+        return (torch.empty((0, 2), dtype=torch.int64, device=home), torch.empty((0,), dtype=torch.int64, device=home))
+    r = torch.cat(parts, dim=0).to(device=home, dtype=torch.int64)
     return r[:, 0:2].contiguous(), r[:, 2].contiguous()
 
 

@@ -114,7 +114,7 @@ int dcx_pred_to_keypoints(const float* d_loc_nchw, const float* d_ids_nchw,
 /* label_to_keypoints model_utils.py:91-124 on caller label maps (class indices, int64 [B][Hc][Wc], as pred_argmax returns them):
  * mask = ids != dust_bin, x = 8*ix + loc%8, y = 8*iy + loc/8, rows in torch.nonzero's raster order -- the second half of
  * dcx_pred_to_keypoints as its own entry, like in the reference.  d_codes: 4 bytes per cell of scratch; d_bad (nullable int32):
- * set to 1 when a label lies outside [0, 255].                                                                            */
+ * set to 1 when a label lies outside [0, 255].  A dust_bin outside [0, 255] equals no label: every cell fires.                                                                            */
 int dcx_label_to_keypoints(const long long* d_loc, const long long* d_ids, int batch, int hc, int wc, int dust_bin, int kmax,
                            int32_t* d_counts, int32_t* d_rows, int32_t* d_codes, int32_t* d_bad, void* stream);
 

@@ -303,8 +303,18 @@ def test_label_to_keypoints_on_label_maps(dev):
     assert torch.equal(k1, k2) and torch.equal(i1, i2) and k1.shape[0] > 20
     with pytest.raises(ValueError):
         label_to_keypoints(torch.full((1, 2, 2), 300, device=dev), torch.zeros((1, 2, 2), dtype=torch.int64, device=dev), 16)
+    # CPU label maps (the reference runs this on dataset labels): processed on the GPU, handed back on the CPU
+    loc_c, ids_c = torch.randint(0, 65, (2, 6, 7), generator=g), torch.randint(0, 17, (2, 6, 7), generator=g)
+    kc, ic = label_to_keypoints(loc_c, ids_c, 16)
+    ekc, eic = O.label_to_keypoints(loc_c, ids_c, 16)
+    assert kc.device.type == "cpu" and torch.equal(kc, ekc.to(torch.int64)) and torch.equal(ic, eic)
+    # a dust_bin no 8-bit label can equal: `ids != dust_bin_ids` is true everywhere -> every cell fires (as in the reference)
+    for db in (-1, 256, 1000):
+        ka, ia_ = label_to_keypoints(loc_c.to(dev), ids_c.to(dev), db)
+        eka, eia = O.label_to_keypoints(loc_c, ids_c, db)
+        assert ka.shape[0] == 2 * 6 * 7 and torch.equal(ka.cpu(), eka.to(torch.int64)) and torch.equal(ia_.cpu(), eia)
     with pytest.raises(ValueError):
-        label_to_keypoints(torch.zeros((1, 2, 2), dtype=torch.int64), torch.zeros((1, 2, 2), dtype=torch.int64), 16)     # CPU tensors: no CPU path
+        label_to_keypoints(loc_c, ids_c.to(dev), 16)                  # maps on different devices
 
 
 def test_extract_patches_border_and_golden(dev, golden):
@@ -986,7 +996,7 @@ def test_colour_bgr_input_through_the_gpu_path(dev, golden_tiny):
     # plant the committed differing pixels (16 x 32) into a corner of the image
     d = np.load(os.path.join(REPO, "tests", "golden", "bgr2gray_formula.npz"))
     bgr[:16, :32] = d["bgr_differ"]
-    variant = imgproc.bgr2gray_variant_of_opencv(imgproc._opencv().__version__) if imgproc._opencv() else imgproc.DEFAULT_BGR2GRAY
+    variant = imgproc.bgr2gray_variant_of_module(imgproc._opencv()) if imgproc._opencv() else imgproc.DEFAULT_BGR2GRAY
     gray = O.bgr2gray(bgr, variant)
     assert int((gray != O.bgr2gray(bgr, "legacy14" if variant == "opencv4" else "opencv4")).sum()) >= 512
     assert np.array_equal(imgproc.bgr2gray(bgr), gray) and not np.array_equal(gray, bgr[..., 1])

@@ -142,12 +142,23 @@ def test_bgr2gray_host():
         assert np.array_equal(imgproc.bgr2gray_fixed_point(d["bgr"], v), d[key])
         assert np.array_equal(imgproc.bgr2gray_fixed_point(d["bgr_differ"], v), d[keyd])
     if imgproc._opencv():      # with OpenCV installed bgr2gray IS cv2.cvtColor: it must agree with the variant of that version
-        v = imgproc.bgr2gray_variant_of_opencv(imgproc._opencv().__version__)
+        v = imgproc.bgr2gray_variant_of_module(imgproc._opencv())          # asks the module itself, not its version string
         assert np.array_equal(bgr2gray(d["bgr_differ"]), imgproc.bgr2gray_fixed_point(d["bgr_differ"], v))
     else:
         assert np.array_equal(bgr2gray(d["bgr"]), d["gray"]) and np.array_equal(bgr2gray(d["bgr_differ"]), d["gray_differ"])
     assert [imgproc.bgr2gray_variant_of_opencv(x) for x in ("4.6.0", "4.11.0.86", "3.4.2", "2.4.13", "weird")] == \
         ["opencv4", "opencv4", "legacy14", "legacy14", "opencv4"]
+
+    class FakeCv2:           # the probe recognises either generation by what it COMPUTES on 16 pixels where the variants differ
+        COLOR_BGR2GRAY = 6
+
+        def __init__(self, variant):
+            self.variant = variant
+
+        def cvtColor(self, img, code):
+            return imgproc.bgr2gray_fixed_point(img, self.variant)
+    assert imgproc._probe_pixels().shape == (1, 16, 3)
+    assert [imgproc.bgr2gray_variant_of_module(FakeCv2(v)) for v in ("opencv4", "legacy14")] == ["opencv4", "legacy14"]
 
 
 def test_checkpoint_reader_never_unpickles_code_silently(tmp_path):
@@ -261,8 +272,8 @@ def test_bgr2gray_formula_against_opencv_when_available():
     this test pins the fixed-point restatement against it on a random colour image."""
     cv2 = pytest.importorskip("cv2")
     from oracle import deepcharuco_oracle as O
-    from deepcharuco_amd.imgproc import bgr2gray_variant_of_opencv
-    variant = bgr2gray_variant_of_opencv(cv2.__version__)       # 4.x (what the reference pins): 15-bit constants; before: 14-bit
+    from deepcharuco_amd.imgproc import bgr2gray_variant_of_module
+    variant = bgr2gray_variant_of_module(cv2)       # what THIS OpenCV computes (4.6 ... 4.11, what the reference pins: 15-bit constants)
     rng = np.random.default_rng(5)
     bgr = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
     assert np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY), O.bgr2gray(bgr, variant))
