@@ -11,7 +11,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 if [ "$MODE" = collect ]; then
     mkdir -p "$OUT"; export TMPDIR=/tmp
-    (cd "$ROOT" && timeout 400 python bench.py --steps 50 --warmup 5 > "$OUT/bench.log" 2>&1; echo "bench exit $?" >> "$OUT/bench.log")
+    (cd "$ROOT" && timeout 700 python bench.py --steps 50 --warmup 5 > "$OUT/bench.log" 2>&1; echo "bench exit $?" >> "$OUT/bench.log")
     cd /tmp
     rm -rf "$OUT"/prof_r${R}*
     B="python $ROOT/bench.py --no-cpu-baseline --no-extras"
@@ -25,6 +25,9 @@ if [ "$MODE" = collect ]; then
     # FETCH_SIZE calibration on known byte counts (tools/ubench/fetch_calib.hip) and the flat-walk A/B of the item order
     timeout 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_calib" -o calib -- $ROOT/tools/ubench/fetch_calib > "$OUT/calib.log" 2>&1
     DCX_XCD_WALK=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_fetch_flat" -o fetch -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_fetch_flat.log" 2>&1
+    # the other single-GPU configs: per-kernel times (their roofline blocks are in bench.log's other_configs)
+    timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}_cfg3" -o cfg3 -- $B --config cfg3 --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_cfg3.log" 2>&1
+    timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}_cfg5" -o cfg5 -- $B --config cfg5 --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_cfg5.log" 2>&1
     # bs=1 (the reference's own protocol): per-kernel times
     timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}_bs1" -o bs1 -- python $ROOT/tools/bs1_loop.py 60 1 > "$OUT/rocprof_bs1.log" 2>&1
     (cd "$ROOT" && timeout 200 python tools/stream_bench.py > "$OUT/stream_bench.log" 2>&1)
@@ -38,6 +41,8 @@ else
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_fetch_flat/fetch_results.db dcx_ > profiles/r${R}_pmc_fetch_size_flat_walk.txt
     python tools/rocprof_summary.py gpurun_out/prof_r${R}_bs1/bs1_results.db | cut -c1-220 > profiles/r${R}_kernel_stats_bs1.txt
     python tools/rocprof_summary.py gpurun_out/prof_r${R}/r${R}_results.db | cut -c1-220 > profiles/r${R}_kernel_stats.txt
+    python tools/rocprof_summary.py gpurun_out/prof_r${R}_cfg3/cfg3_results.db | cut -c1-220 > profiles/r${R}_kernel_stats_cfg3.txt
+    python tools/rocprof_summary.py gpurun_out/prof_r${R}_cfg5/cfg5_results.db | cut -c1-220 > profiles/r${R}_kernel_stats_cfg5.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_fetch/fetch_results.db dcx_ > profiles/r${R}_pmc_fetch_size.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_write/write_results.db dcx_ > profiles/r${R}_pmc_write_size.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_sq/sq_results.db dcx_conv > profiles/r${R}_pmc_sq.txt
