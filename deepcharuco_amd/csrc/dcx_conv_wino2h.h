@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
             // the SIMD arbiter prefers the OLDER of a CU's two workgroups, which then finishes its items ~16 % earlier and leaves the
             // other one alone at the end: take turns instead -- priority follows a bit of the real-time clock,
             // inverted for the second-dispatched half of the grid
-            const unsigned rt = (unsigned)__builtin_amdgcn_s_memrealtime();
+            const unsigned rt = (unsigned)__builtin_amdgcn_s_memrealtime();     // (read one unit ahead of its use -- no s_waitcnt at the
+                                                                                 //  unit head -- measured in round 5: within the noise)
             const bool hi = (((rt >> DCX_PRIO_FLIP) & 1u) != 0u) != (blockIdx.x >= (gridDim.x >> 1));
             if (hi) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
