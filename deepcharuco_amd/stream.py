@@ -24,7 +24,7 @@ from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, packed_len
 class FrameStream:
     def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 32, height: int = 240,
                  width: int = 320, kmax: int = DEFAULT_KMAX, depth: int = 2, pnp: Optional[dict] = None,
-                 compute_streams: int = 1, bgr: bool = False):
+                 compute_streams: int = 1, bgr: bool = False, h2d_on_compute: bool = False):
         """``bgr=True``: the stream is fed (n,H,W,3) BGR frames, as the reference's callers hold them (pose_estimation.py:53-59);
         the colour conversion of inference.py:40 happens on the device inside the first layer's load.  ``kmax``: the AVERAGE
         number of corners per frame the buffers are sized for -- the corner pool of a batch holds ``batch * kmax`` corners and a
@@ -35,6 +35,7 @@ class FrameStream:
         self.batch, self.h, self.w, self.kmax, self.depth = batch, height, width, kmax, depth
         self.pool = batch * kmax
         self.bgr = bool(bgr)
+        self.h2d_on_compute = bool(h2d_on_compute)     # upload on the batch's own compute stream instead of the shared copy stream
         self.pnp = pnp
         if not (1 <= compute_streams <= depth):
             raise ValueError("compute_streams must be between 1 and depth")
@@ -85,12 +86,17 @@ class FrameStream:
             self.pin_in[slot][n:].zero_()
         with torch.cuda.device(self.dev):
             compute = torch.cuda.current_stream() if self.compute is None else self.compute[self._ticket % len(self.compute)]
-            with torch.cuda.stream(self.copy_stream):
-                self.copy_stream.wait_event(self.ev_free[slot])         # previous user of dev_in[slot] is done
-                self.dev_in[slot].copy_(self.pin_in[slot], non_blocking=True)
-                self.ev_h2d[slot].record(self.copy_stream)
+            if not self.h2d_on_compute:
+                with torch.cuda.stream(self.copy_stream):
+                    self.copy_stream.wait_event(self.ev_free[slot])         # previous user of dev_in[slot] is done
+                    self.dev_in[slot].copy_(self.pin_in[slot], non_blocking=True)
+                    self.ev_h2d[slot].record(self.copy_stream)
             with torch.cuda.stream(compute):
-                compute.wait_event(self.ev_h2d[slot])
+                if self.h2d_on_compute:
+                    compute.wait_event(self.ev_free[slot])
+                    self.dev_in[slot].copy_(self.pin_in[slot], non_blocking=True)
+                else:
+                    compute.wait_event(self.ev_h2d[slot])
                 infer_batch_device(self.dev_in[slot], self.dust_bin_ids, self.deepc, self.refinenet, out=self.dev_out[slot],
                                    pool=self.pool)
                 self.ev_free[slot].record(compute)

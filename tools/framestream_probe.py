@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Why does FrameStream(compute_streams=2) not reach what two plain streams reach (bench.py cfg2_two_batches_in_flight)?"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepcharuco_amd import weights as W, workload as WL
+from deepcharuco_amd.inference import infer_batch_device, packed_len
+from deepcharuco_amd.stream import FrameStream
+from deepcharuco_amd.models.net import dcModel, lModel
+from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+dev = torch.device("cuda", 0)
+B, NB = 32, 60
+frames = W.synthetic_frames("board", 1000, B, 240, 320)
+sd = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames).to(dev), dev)
+dc, rn = lModel(dcModel(16, sd, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
+
+def fs_run(name, **kw):
+    fs = FrameStream(16, dc, rn, batch=B, height=240, width=320, **kw)
+    list(fs.run([frames] * 4))
+    best = 0
+    for _ in range(3):
+        t = time.time()
+        n = sum(len(item[1]) for item in fs.run([frames] * NB))
+        best = max(best, n / (time.time() - t))
+    print(f"{name:70s} {best:8.0f} fps", flush=True)
+
+def plain(name, nstreams, h2d):
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    pin = [torch.from_numpy(frames).pin_memory() for _ in range(nstreams)]
+    d = [torch.empty((B, 240, 320), dtype=torch.uint8, device=dev) for _ in range(nstreams)]
+    n = packed_len(B, B * 64)
+    out = [torch.empty((n,), dtype=torch.int32, device=dev) for _ in range(nstreams)]
+    host = [torch.empty((n,), dtype=torch.int32).pin_memory() for _ in range(nstreams)]
+    def step(i):
+        k = i % nstreams
+        with torch.cuda.stream(streams[k]):
+            if h2d:
+                d[k].copy_(pin[k], non_blocking=True)
+            infer_batch_device(d[k], 16, dc, rn, out=out[k], pool=B * 64)
+            host[k].copy_(out[k], non_blocking=True)
+    for i in range(6): step(i)
+    torch.cuda.synchronize()
+    best = 0
+    for _ in range(3):
+        t = time.time()
+        for i in range(NB): step(i)
+        torch.cuda.synchronize()
+        best = max(best, B * NB / (time.time() - t))
+    print(f"{name:70s} {best:8.0f} fps", flush=True)
+
+plain("plain loop, 1 stream, no H2D", 1, False)
+plain("plain loop, 2 streams, no H2D (= bench two_batches_in_flight)", 2, False)
+plain("plain loop, 2 streams, H2D on the same stream", 2, True)
+fs_run("FrameStream depth=3 compute_streams=2", depth=3, compute_streams=2)
+fs_run("FrameStream depth=3 compute_streams=2 h2d_on_compute", depth=3, compute_streams=2, h2d_on_compute=True)
+fs_run("FrameStream depth=4 compute_streams=2 h2d_on_compute", depth=4, compute_streams=2, h2d_on_compute=True)
+fs_run("FrameStream depth=2 compute_streams=2 h2d_on_compute", depth=2, compute_streams=2, h2d_on_compute=True)
+fs_run("FrameStream depth=2 compute_streams=1", depth=2, compute_streams=1)
+fs_run("FrameStream depth=2 compute_streams=1 h2d_on_compute", depth=2, compute_streams=1, h2d_on_compute=True)
