@@ -24,7 +24,7 @@ from .inference import DEFAULT_KMAX, infer_batch, infer_batch_device, packed_len
 class FrameStream:
     def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 32, height: int = 240,
                  width: int = 320, kmax: int = DEFAULT_KMAX, depth: int = 2, pnp: Optional[dict] = None,
-                 compute_streams: int = 1, bgr: bool = False, h2d_on_compute: bool = False):
+                 compute_streams: int = 1, bgr: bool = False, h2d_on_compute: Optional[bool] = None):
         """``bgr=True``: the stream is fed (n,H,W,3) BGR frames, as the reference's callers hold them (pose_estimation.py:53-59);
         the colour conversion of inference.py:40 happens on the device inside the first layer's load.  ``kmax``: the AVERAGE
         number of corners per frame the buffers are sized for -- the corner pool of a batch holds ``batch * kmax`` corners and a
@@ -35,7 +35,9 @@ class FrameStream:
         self.batch, self.h, self.w, self.kmax, self.depth = batch, height, width, kmax, depth
         self.pool = batch * kmax
         self.bgr = bool(bgr)
-        self.h2d_on_compute = bool(h2d_on_compute)     # upload on the batch's own compute stream instead of the shared copy stream
+        # upload on the batch's own compute stream instead of the shared copy stream: default with several compute streams (+5 % in
+        # that mode); with one compute stream the separate copy stream is 0.7 % ahead (profiles/experiments/r05_two_streams_with_uploads.md)
+        self.h2d_on_compute = compute_streams > 1 if h2d_on_compute is None else bool(h2d_on_compute)
         self.pnp = pnp
         if not (1 <= compute_streams <= depth):
             raise ValueError("compute_streams must be between 1 and depth")
@@ -44,8 +46,10 @@ class FrameStream:
         with torch.cuda.device(self.dev):
             self.copy_stream = torch.cuda.Stream()
             # compute_streams = 2: consecutive batches run the pipeline on alternating streams, so batch i+1's detector
-            # kernels fill the CUs that batch i's small RefineNet launches / ramps / partial last rounds leave idle
-            # (+7 % frames/s at bs=32, tools/two_stream_probe.py); the pipeline scratch is per (model, stream)
+            # kernels fill the CUs that batch i's small RefineNet launches / ramps / partial last rounds leave idle: +7 ... +15 %
+            # frames/s at bs=32 WHEN THE FRAMES ARE ALREADY IN HBM (bench.py cfg2_two_batches_in_flight).  Fed over PCIe, as this
+            # class is, the gain does not materialise (10.3 k vs 10.2 k on one stream, tools/framestream_probe.py) -- the default
+            # stays 1; the pipeline scratch is per (model, stream)
             self.compute = [torch.cuda.Stream() for _ in range(compute_streams)] if compute_streams > 1 else None
             self.pin_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
             self.dev_in = [torch.empty(shape, dtype=torch.uint8, device=self.dev) for _ in range(depth)]

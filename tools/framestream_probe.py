@@ -3,8 +3,8 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from deepcharuco_amd import weights as W, workload as WL
-from deepcharuco_amd.inference import infer_batch_device, packed_len
+from deepcharuco_amd import _lib, weights as W, workload as WL
+from deepcharuco_amd.inference import infer_batch_device, launch_pipeline, packed_len
 from deepcharuco_amd.stream import FrameStream
 from deepcharuco_amd.models.net import dcModel, lModel
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
@@ -34,9 +34,16 @@ def plain(name, nstreams, h2d):
     def step(i):
         k = i % nstreams
         with torch.cuda.stream(streams[k]):
-            if h2d:
+            if h2d == "kernel":       # (needs the dcx_upload_u8 entry of profiles/experiments/r05_two_streams_with_uploads.md)
+                _lib.check(_lib.lib().dcx_upload_u8(pin[k].data_ptr(), d[k].data_ptr(), d[k].numel(), _lib.current_stream()), "upload")
+            elif h2d:
                 d[k].copy_(pin[k], non_blocking=True)
-            infer_batch_device(d[k], 16, dc, rn, out=out[k], pool=B * 64)
+            if h2d == "zerocopy":       # the kernels read the frames straight out of pinned host memory
+                det, ref = dc.model, rn.model
+                nb = _lib.lib().dcx_pipeline_workspace_bytes(det.handle, ref.handle, B, 240, 320, B * 64)
+                launch_pipeline(det, ref, pin[k].data_ptr(), B, 240, 320, 1, 0, 16, B * 64, det._ws.get("pipe", dev, nb), out[k].data_ptr())
+            else:
+                infer_batch_device(d[k], 16, dc, rn, out=out[k], pool=B * 64)
             host[k].copy_(out[k], non_blocking=True)
     for i in range(6): step(i)
     torch.cuda.synchronize()
@@ -51,6 +58,9 @@ def plain(name, nstreams, h2d):
 plain("plain loop, 1 stream, no H2D", 1, False)
 plain("plain loop, 2 streams, no H2D (= bench two_batches_in_flight)", 2, False)
 plain("plain loop, 2 streams, H2D on the same stream", 2, True)
+plain("plain loop, 1 stream, H2D copy", 1, True)
+plain("plain loop, 1 stream, zero-copy frames (pinned host memory)", 1, "zerocopy")
+plain("plain loop, 2 streams, zero-copy frames (pinned host memory)", 2, "zerocopy")
 fs_run("FrameStream depth=3 compute_streams=2", depth=3, compute_streams=2)
 fs_run("FrameStream depth=3 compute_streams=2 h2d_on_compute", depth=3, compute_streams=2, h2d_on_compute=True)
 fs_run("FrameStream depth=4 compute_streams=2 h2d_on_compute", depth=4, compute_streams=2, h2d_on_compute=True)
