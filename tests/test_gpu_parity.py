@@ -1063,6 +1063,26 @@ def test_c_abi_error_codes(dev, golden_tiny):
     with pytest.raises(AssertionError):
         rn.infer_patches(torch.zeros((2, 20, 24), device=dev), torch.zeros((2, 2), dtype=torch.int64, device=dev))
     assert rn.infer_patches(torch.zeros((0, 24, 24), device=dev), torch.zeros((0, 2), dtype=torch.int64, device=dev))[1].shape == (0, 2)
+    # the whole-path entry (round 5 signature: pixel format, corner pool, starts, optional confidences)
+    pool = 8
+    pw = torch.empty(L.dcx_pipeline_workspace_bytes(det.handle, rn.handle, 1, 64, 96, pool), dtype=torch.uint8, device=dev)
+    cnt, st = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    rows, xy = torch.zeros((pool, 4), dtype=torch.int32, device=dev), torch.zeros((pool, 2), device=dev)
+
+    def call(frames_p=frames.data_ptr(), stride=64 * 96, pitch=96, pix=0, b=1, h=64, w=96, dust=16, pool_=pool, ws_n=None,
+             counts=cnt.data_ptr(), starts=st.data_ptr(), rows_p=rows.data_ptr(), xy_p=xy.data_ptr(), rf=rn.handle):
+        return L.dcx_infer_batch(det.handle, rf, frames_p, stride, pitch, pix, b, h, w, dust, pool_, pw.data_ptr(),
+                                 pw.numel() if ws_n is None else ws_n, counts, starts, rows_p, xy_p, None, None)
+    assert call() == 0
+    torch.cuda.synchronize()
+    assert call(frames_p=None) == -1 and call(counts=None) == -1 and call(starts=None) == -1 and call(rows_p=None) == -1
+    assert call(xy_p=None) == -1 and call(xy_p=None, rf=None) == 0            # xy is required exactly when a RefineNet is given
+    assert call(pix=3) == -1 and call(pix=-1) == -1                           # unknown pixel format
+    assert call(pool_=0) == -2 and call(pool_=(1 << 22) + 1) == -2 and call(h=4) == -2 and call(b=0) == -2
+    assert call(pitch=95) == -2 and call(pix=1, pitch=96) == -2               # a row does not fit its pitch (BGR needs 3 bytes per pixel)
+    assert call(ws_n=1024) == -3 and call(dust=256) == -4 and call(dust=-1) == -4
+    assert L.dcx_pipeline_workspace_bytes(det.handle, rn.handle, 1, 64, 96, 0) == 0
+    torch.cuda.synchronize()
 
 
 def test_frame_stream_matches_oracle(dev):
