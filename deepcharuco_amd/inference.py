@@ -9,7 +9,7 @@ and exists so every mirrored function is exercised end to end; both return ident
 from __future__ import annotations
 
 import warnings
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 import numpy as np
 import torch
