@@ -102,6 +102,8 @@ def oracle_chunk(spec):
     # ---- the reference against ITSELF (1): one frame per call, same thread count (inference.py:32-70 is per frame) -- every 4th frame
     loc_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[0] for b in sub])
     ids_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[1] for b in sub])
+    # ---- exact arithmetic: the same graph in float64 on the same float32 inputs and weights ("truth" for BOTH fp32 evaluations)
+    loc64, ids64 = O.detector_forward({k_: v.double() for k_, v in t_dc.items()}, x.double())
     # ---- the reference against ITSELF (2): the same tensors, one thread
     torch.set_num_threads(1)
     loc_1t, ids_1t = O.detector_forward(t_dc, x)
@@ -114,7 +116,7 @@ def oracle_chunk(spec):
              heat_idx=cat(heat_idx, np.int64), heat_margin=cat(heat_margin, np.float32), sub=np.array(sub),
              finals=np.array(finals, dtype=object), wseed=wseed, cid=cid,
              loc_1t=loc_1t.numpy(), ids_1t=ids_1t.numpy(), heat_idx_1t=heat_idx_1t, finals_1t=np.array(finals_1t, dtype=object),
-             loc_b1=loc_b1.numpy(), ids_b1=ids_b1.numpy())
+             loc_b1=loc_b1.numpy(), ids_b1=ids_b1.numpy(), loc64=loc64.numpy(), ids64=ids64.numpy())
     return path
 
 
@@ -140,8 +142,11 @@ def main():
     nb = len(EDGES) - 1
     zero = lambda: {"cells": np.zeros(nb, np.int64), "disagree": np.zeros(nb, np.int64)}
     COLS = ("hip_default", "hip_direct", "oracle_1thr", "oracle_bs1")
+    # second group: everybody against EXACT arithmetic (the oracle's graph in float64 on the same fp32 inputs / weights), bucketed by
+    # the float64 pass's margins -- how far is each fp32 evaluation from the truth they both approximate?
+    COLS64 = ("oracle_f32_vs_f64", "hip_default_vs_f64", "hip_direct_vs_f64")
     col = {c: {"stats": {"loc": zero(), "ids": zero(), "heat": zero(), "fire": zero()}, "max_abs_logit_diff": 0.0, "sum_abs": 0.0,
-               "count": 0, "cells_decided_differently": 0, "e2e_frames": 0, "e2e_bad": 0, "e2e_corners": 0, "frames": 0} for c in COLS}
+               "count": 0, "cells_decided_differently": 0, "e2e_frames": 0, "e2e_bad": 0, "e2e_corners": 0, "frames": 0} for c in COLS + COLS64}
     ids_hist = np.zeros(N_IDS, np.int64)
     per_res = {}
     frames_done = chunks_done = 0
@@ -152,11 +157,11 @@ def main():
         C = col[c]
         C["frames"] += g_loc.shape[0]
         for name, g, o in (("loc", g_loc, o_loc), ("ids", g_ids, o_ids)):
-            diff = (g - o).abs()
+            diff = (g.to(o.dtype) - o).abs()
             C["max_abs_logit_diff"] = max(C["max_abs_logit_diff"], float(diff.max()))
             C["sum_abs"] += float(diff.sum()); C["count"] += diff.numel()
             top = torch.topk(o, 2, dim=1).values
-            bucket = torch.bucketize((top[:, 0] - top[:, 1]).flatten(), edges, right=True)
+            bucket = torch.bucketize((top[:, 0] - top[:, 1]).flatten(), edges.to(o.dtype), right=True)
             bad = (g.argmax(1) != o.argmax(1)).flatten()
             C["stats"][name]["cells"] += torch.bincount(bucket, minlength=nb).cpu().numpy()
             C["stats"][name]["disagree"] += torch.bincount(bucket[bad], minlength=nb).cpu().numpy()
@@ -166,7 +171,7 @@ def main():
         C["cells_decided_differently"] += int(((fire_o != fire_g) | (fire_o & ((o_la != g_la) | (o_ia != g_ia)))).sum())
         # fire / no-fire by the distance of the oracle's decision from its threshold (cells whose loc head fires)
         fm = (o_ids[:, :N_IDS].max(1).values - o_ids[:, N_IDS]).abs()[o_la != 64]
-        bucket = torch.bucketize(fm, edges, right=True)
+        bucket = torch.bucketize(fm, edges.to(fm.dtype), right=True)
         C["stats"]["fire"]["cells"] += torch.bincount(bucket, minlength=nb).cpu().numpy()
         C["stats"]["fire"]["disagree"] += torch.bincount(bucket[(fire_o != fire_g)[o_la != 64]], minlength=nb).cpu().numpy()
         return fire_o, o_ia
@@ -199,7 +204,9 @@ def main():
                "columns": {"hip_default": "product path (Winograd families) vs the reference pass",
                            "hip_direct": "product path, deterministic mode (direct family) vs the reference pass",
                            "oracle_1thr": "the oracle itself with torch.set_num_threads(1) vs the reference pass",
-                           "oracle_bs1": "the oracle one frame per call (every 4th frame; logits only) vs the reference pass"},
+                           "oracle_bs1": "the oracle one frame per call (every 4th frame; logits only) vs the reference pass",
+                           "oracle_f32_vs_f64": "the reference pass itself vs EXACT arithmetic (the oracle's graph in float64 on the same fp32 inputs / weights)",
+                           "hip_default_vs_f64": "product path vs exact arithmetic", "hip_direct_vs_f64": "product path, direct family, vs exact arithmetic"},
                "firing_cells_per_id": ids_hist.tolist(),
                "weight_sets": "61 seeds; a third of the chunks with the ids-head biases equalised per class (all 16 ids fire); every second chunk "
                               "with the dust-bin threshold within +-2e-4 of a cell's own margin (fire/no-fire sampled where it is close)",
@@ -230,9 +237,12 @@ def main():
                 xs = torch.stack([torch.from_numpy(pre_bgr_image(frames[b])) for b in sub]).to(dev)       # (S,1,h,w)
                 pos = {int(b): i for i, b in enumerate(sub)}
                 patches = torch.cat([extract_patches(xs[pos[int(b)]], torch.from_numpy(kp[kf == b]).to(dev)) for b in np.unique(kf)])
+            t_loc, t_ids = torch.from_numpy(z["loc64"]).to(dev), torch.from_numpy(z["ids64"]).to(dev)
+            compare_logits("oracle_f32_vs_f64", o_loc, o_ids, t_loc, t_ids)
             for c, direct in (("hip_default", False), ("hip_direct", True)):
                 set_deterministic(direct)
                 got = det.forward_u8(d_frames)
+                compare_logits(c + "_vs_f64", got["loc"], got["ids"], t_loc, t_ids)
                 fire_o, o_ia = compare_logits(c, got["loc"], got["ids"], o_loc, o_ids)
                 if c == "hip_default":
                     ids_hist += torch.bincount(o_ia[fire_o], minlength=N_IDS + 1)[:N_IDS].cpu().numpy()
@@ -265,6 +275,12 @@ def main():
     print(f"{'mean |logit diff|':24s}" + "".join(f"{col[c]['mean_abs_logit_diff']:16.3e}" for c in COLS))
     print(f"{'cells decided differently':24s}" + "".join(f"{col[c]['cells_decided_differently']:16d}" for c in COLS))
     print(f"{'e2e frames differing':24s}" + "".join(f"{str(col[c]['end_to_end']['mismatched_frames']) + '/' + str(col[c]['end_to_end']['frames']):>16s}" for c in COLS))
+    print("\nagainst EXACT arithmetic (float64 evaluation of the same graph; margins of the float64 pass):")
+    print(f"{'':24s}" + "".join(f"{c:>22s}" for c in COLS64))
+    print(f"{'max |logit diff|':24s}" + "".join(f"{col[c]['max_abs_logit_diff']:22.3e}" for c in COLS64))
+    print(f"{'mean |logit diff|':24s}" + "".join(f"{col[c]['mean_abs_logit_diff']:22.3e}" for c in COLS64))
+    print(f"{'loc+ids arg-max flips':24s}" + "".join(f"{sum(col[c]['histogram']['loc']['differs']) + sum(col[c]['histogram']['ids']['differs']):22d}" for c in COLS64))
+    print(f"{'cells decided differently':24s}" + "".join(f"{col[c]['cells_decided_differently']:22d}" for c in COLS64))
     for name, title in (("loc", "loc 65-way arg-max"), ("ids", "ids 17-way arg-max"), ("heat", "RefineNet 4096-way arg-max"), ("fire", "fire / no-fire (by |ids max - dust-bin|)")):
         print(f"\n{title}: decided by the reference pass | differs in column")
         print(f"{'oracle margin':>22s} | {'decided':>12s} |" + "".join(f"{c:>14s}" for c in COLS))
