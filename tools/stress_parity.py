@@ -103,7 +103,12 @@ def oracle_chunk(spec):
     loc_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[0] for b in sub])
     ids_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[1] for b in sub])
     # ---- exact arithmetic: the same graph in float64 on the same float32 inputs and weights ("truth" for BOTH fp32 evaluations)
-    loc64, ids64 = O.detector_forward({k_: v.double() for k_, v in t_dc.items()}, x.double())
+    # (in slices of <= 1.3 M pixels: float64 activations of a whole chunk would be 2x the fp32 pass's memory in every worker)
+    t64 = {k_: v.double() for k_, v in t_dc.items()}
+    step = max(1, (1 << 20) * 5 // 4 // (h * w))
+    parts = [O.detector_forward(t64, x[i:i + step].double()) for i in range(0, n, step)]
+    loc64, ids64 = torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
+    del parts, t64
     # ---- the reference against ITSELF (2): the same tensors, one thread
     torch.set_num_threads(1)
     loc_1t, ids_1t = O.detector_forward(t_dc, x)

@@ -21,3 +21,14 @@ print("|---|---:|" + "---:|" * 3)
 for i, lab in enumerate(d["buckets"]):
     dec = R["hip_default"]["histogram"]["loc"]["decided"][i] + R["hip_default"]["histogram"]["ids"]["decided"][i]
     print(f"| {lab} | {dec:,} | " + " | ".join(str(R[c]["histogram"]["loc"]["differs"][i] + R[c]["histogram"]["ids"]["differs"][i]) for c in cols[:3]) + " |")
+c64 = [c for c in ("oracle_f32_vs_f64", "hip_default_vs_f64", "hip_direct_vs_f64") if c in R]
+if c64:
+    n64 = {"oracle_f32_vs_f64": "the reference pass (oracle fp32)", "hip_default_vs_f64": "HIP default", "hip_direct_vs_f64": "HIP direct family"}
+    print("\nagainst EXACT arithmetic (the oracle's graph in float64 on the same fp32 inputs and weights):\n")
+    print("| vs float64 | " + " | ".join(n64[c] for c in c64) + " |")
+    print("|---|" + "---:|" * len(c64))
+    print("| largest logit error | " + " | ".join(f"{R[c]['max_abs_logit_diff']:.2e}" for c in c64) + " |")
+    print("| mean logit error | " + " | ".join(f"{R[c]['mean_abs_logit_diff']:.2e}" for c in c64) + " |")
+    print("| arg-max decisions that differ from the exact ones (`loc` + `ids`) | " + " | ".join(
+        str(sum(R[c]['histogram']['loc']['differs']) + sum(R[c]['histogram']['ids']['differs'])) for c in c64) + " |")
+    print("| cells whose final decision differs from the exact one | " + " | ".join(str(R[c]["cells_decided_differently"]) for c in c64) + " |")
