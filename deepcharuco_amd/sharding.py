@@ -164,7 +164,7 @@ def unpack_gathered(gathered: np.ndarray, n_frames: int, world: int, pool: int, 
 
 def infer_frames_sharded(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, kmax: int = 64,
                          group=None, run_local=None, pool: Optional[int] = None):
-    """Collective version of ``inference.infer_batch``: every rank passes the same (B,H,W) host
+    """Collective version of ``inference.infer_batch``: every rank passes the same (B,H,W) gray or (B,H,W,3) BGR host
     array (or at least its own slice), processes frames [lo,hi) and receives ALL results.
 
     ``run_local(frames_slice, pool) -> packed int32 tensor`` defaults to the HIP pipeline; the gloo CPU
@@ -204,8 +204,8 @@ def infer_frames_sharded(frames_gray: np.ndarray, dust_bin_ids: int, deepc, refi
 
 def infer_batches_sharded(batches, dust_bin_ids: int, deepc, refinenet=None, kmax: int = 64, group=None,
                           backend: Optional[str] = None, depth: int = 2):
-    """Pipelined collective caller: ``batches`` is an iterable of (B,H,W) uint8 host arrays of ONE shape (every rank
-    passes the same sequence); yields, in order, the list of B keypoint arrays of each batch on every rank.
+    """Pipelined collective caller: ``batches`` is an iterable of (B,H,W) gray or (B,H,W,3) BGR uint8 host arrays of ONE shape
+    (every rank passes the same sequence); yields, in order, the list of B keypoint arrays of each batch on every rank.
 
     Batch i+1's upload and kernels are enqueued before batch i's gathered corner lists are waited for, and the gather
     itself runs on :class:`OverlappedGather`'s side stream, so the exchange step costs no GPU time on the compute
@@ -229,16 +229,18 @@ def infer_batches_sharded(batches, dust_bin_ids: int, deepc, refinenet=None, kma
 
     for frames in batches:
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
-        n, h, w = frames.shape
+        if not (frames.ndim == 3 or (frames.ndim == 4 and frames.shape[3] == 3)):
+            raise ValueError("expected (B,H,W) gray or (B,H,W,3) BGR uint8 frames")
+        n = frames.shape[0]
         lo, hi = shard_range(n, rank, world)
         bmax = shard_range(n, 0, world)[1]
         if og is None:
-            shape0 = (n, h, w)
+            shape0 = frames.shape
             pool = max(1, bmax * kmax)
             og = OverlappedGather(packed_len(bmax, pool), dev, group, backend, depth)
-        elif (n, h, w) != shape0:
+        elif frames.shape != shape0:
             raise ValueError("infer_batches_sharded needs batches of one shape; flush and start a new call")
-        local = np.zeros((bmax, h, w), np.uint8)
+        local = np.zeros((bmax,) + frames.shape[1:], np.uint8)
         local[:hi - lo] = frames[lo:hi]
         if len(pending) == depth:                       # the slot about to be reused: hand its results out first
             j, fj = pending.pop(0)

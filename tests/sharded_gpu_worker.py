@@ -55,6 +55,11 @@ def main():
     res_pipe = list(infer_batches_sharded(batches, 16, dc, rn, kmax=64))
     # empty shard: 1 frame over 2 ranks
     res_one = infer_frames_sharded(frames[:1], 16, dc, rn, kmax=64)
+    # BGR frames (what the reference's callers hold): gray replicated x3 converts back to itself, so the results must not change;
+    # and pools far too small (2 slots per frame): both ranks repeat the batch collectively with the pool the first pass reported
+    bgr = np.ascontiguousarray(np.repeat(frames[..., None], 3, axis=3))
+    res_bgr = infer_frames_sharded(bgr, 16, dc, rn, kmax=64)
+    (res_bgr_pipe,) = list(infer_batches_sharded([bgr], 16, dc, rn, kmax=2))
 
     verdict = None
     if rank == 0:
@@ -71,13 +76,14 @@ def main():
                        split=[shard_range(n_frames, r, world) for r in range(world)],
                        corners=int(sum(e.shape[0] for e in exp if e.ndim == 2)),
                        mismatched_single=int(bad_single), mismatched_pipelined=int(bad_pipe),
-                       pipelined_batches=len(res_pipe), one_frame_ok=bool(len(res_one) == 1 and same(res_one[0], exp[0])))
+                       pipelined_batches=len(res_pipe), one_frame_ok=bool(len(res_one) == 1 and same(res_one[0], exp[0])),
+                       mismatched_bgr=int(sum(not same(a, b) for a, b in zip(res_bgr, exp)) + sum(not same(a, b) for a, b in zip(res_bgr_pipe, exp))))
         with open(out_path, "w") as f:
             json.dump(verdict, f)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        ok = verdict["mismatched_single"] == 0 and verdict["mismatched_pipelined"] == 0 and verdict["one_frame_ok"] \
+        ok = verdict["mismatched_single"] == 0 and verdict["mismatched_pipelined"] == 0 and verdict["one_frame_ok"] and verdict["mismatched_bgr"] == 0 \
             and verdict["corners"] > 50
         sys.exit(0 if ok else 4)
 

@@ -94,20 +94,20 @@ def test_world8_cfg5_full_size_every_rank_checked(tmp_path):
 def test_two_ranks_on_one_gpu_gloo_real_kernels(tmp_path):
     v = _launch("gloo", 2, tmp_path)
     assert v["world"] == 2 and v["split"] == [[0, 6], [6, 11]]
-    assert v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["one_frame_ok"] and v["corners"] > 50
+    assert v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["mismatched_bgr"] == 0 and v["one_frame_ok"] and v["corners"] > 50
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box has one")
 def test_two_ranks_rccl_real_kernels(tmp_path):
     v = _launch("nccl", 2, tmp_path)
-    assert v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["one_frame_ok"]
+    assert v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["mismatched_bgr"] == 0 and v["one_frame_ok"]
 
 
 def test_one_rank_rccl_real_kernels(tmp_path):
     """RCCL itself on the 1-GPU box: a process group of ONE rank runs the same product path (all_gather_into_tensor on the
     side stream, double-buffered, barrier) -- what the 8-GPU job does per rank, minus the peers."""
     v = _launch("nccl", 1, tmp_path)
-    assert v["world"] == 1 and v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["one_frame_ok"] and v["corners"] > 50
+    assert v["world"] == 1 and v["mismatched_single"] == 0 and v["mismatched_pipelined"] == 0 and v["mismatched_bgr"] == 0 and v["one_frame_ok"] and v["corners"] > 50
 
 
 def test_bench_n_gt_1_code_path_with_one_rccl_rank(tmp_path):
