@@ -11,6 +11,12 @@ one RCCL all-gather of the packed corner lists, issued on a side stream so that 
 convolutions) over one batch of synthetic gray frames ALREADY RESIDENT in HBM, ending with the async D2H of the packed
 result into pinned host memory.  Weak scaling: every rank processes the same number of frames per step for every N
 (32 by default = BASELINE configs[1] per GPU), so the driver's 1/2/4/8-GPU values form a true weak-scaling curve.
+The K timed steps go through the product's non-blocking caller for HBM-resident frames (stream.ResidentStream; at N>1
+the same launches under sharding.OverlappedGather's side-stream gather) on ONE HIP stream.  `--streams S` alternates
+consecutive steps between S streams (S batches in flight); the roofline block is then measured in a second pass of the
+same K steps on one stream (`single_stream`).  Rounds 2-5 reported "+6 ... +15 % with two batches in flight": that was a
+measurement artifact -- the second batch of that comparison came from another seed and fired 38 % fewer corners; with
+equal work in every batch a second stream LOSES 1-4 % (profiles/experiments/r05_batches_in_flight_equal_work.txt).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with
   roofline        dominant kernel, hipEvent-timed inside the timed region;
@@ -40,6 +46,7 @@ from deepcharuco_amd.inference import infer_batch_device, infer_image, packed_le
 from deepcharuco_amd.models.net import dcModel, lModel  # noqa: E402
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet  # noqa: E402
 from deepcharuco_amd.sharding import OverlappedGather  # noqa: E402
+from deepcharuco_amd.stream import ResidentStream  # noqa: E402
 
 METRIC = "frames/sec end-to-end (detect+refine) at 320x240; corner-id match vs ref"
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -187,7 +194,11 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     if fixed_k:
         frames, kept = WL.select_fixed_k_frames(frames_kind, seed0, B, H, Wd, fixed_k, dc, dev, max_candidates=20000)
     else:
-        frames = W.synthetic_frames(frames_kind, seed0, B, H, Wd)
+        # Weak scaling needs the SAME work on every rank.  The dust-bin calibration fits the frames it was run on: rank 0's batch
+        # fires 16.0 cells per frame, another seed's frames 9.9 under the same weights (tools/resident_stream_probe.py) -- i.e. 23
+        # instead of 26.8 GFLOP per frame.  So every rank processes rank 0's frames, rotated by its rank: frame b of rank r is
+        # frame (b + r) % B of rank 0 (rounds 1-5 gave every rank its own seed, which made ranks > 0 ~15 % lighter).
+        frames = np.roll(W.synthetic_frames(frames_kind, FRAME_SEED, B, H, Wd), -rank, axis=0)
     d_frames = torch.from_numpy(frames).to(dev)
     kept_all = None
     if fixed_k and (world > 1 or cx.force_dist):
@@ -200,30 +211,49 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     # reference refines every firing cell, inference.py:51-57); kmax is only the AVERAGE the buffers are sized for
     pool = B * kmax
     n_i32 = packed_len(B, pool)
-    host_local = torch.empty((n_i32,), dtype=torch.int32).pin_memory()
     dist_on = world > 1 or cx.force_dist      # --force-dist: the N>1 code path (process group, side-stream gather, barrier) with ONE rank
     og = OverlappedGather(n_i32, dev, backend=cx.backend) if dist_on else None
     if og is not None:
         og.warm_up()      # RCCL's lazy initialisation (tens of ms over its first dozens of calls) is not steady-state throughput
-    out_single = torch.empty((n_i32,), dtype=torch.int32, device=dev)
-    state = {"i": 0}
+    # Batches in flight: consecutive steps run on alternating HIP streams (the product's pipelined callers: stream.ResidentStream
+    # at N = 1, the same alternation under the side-stream gather at N > 1), so that batch i+1's convolutions fill the matrix
+    # cores that batch i's HBM-bound / small launches, ramps and partial last rounds leave idle.  Every step is still one whole
+    # pass of the path over one batch; bit-identical results (frames are independent, the default kernels are batch invariant).
+    S = max(1, int(cx.streams))
+    if og is not None:
+        S = min(S, og.depth)
+    state = {"i": 0, "last": None, "S": S}
+    rs_of = {}                                  # ResidentStream per stream count (N = 1)
+    cs = [torch.cuda.Stream() for _ in range(S)] if og is not None else None
+    torch.cuda.synchronize()                    # d_frames / weights were produced on the default stream
+
+    def resident(n_streams):
+        if n_streams not in rs_of:
+            rs_of[n_streams] = ResidentStream(16, dc, rn, batch=B, height=H, width=Wd, kmax=kmax, compute_streams=n_streams, raw=True)
+        return rs_of[n_streams]
 
     def step():
         i = state["i"]; state["i"] += 1
         if og is None:
-            packed = infer_batch_device(d_frames, 16, dc, rn, out=out_single, pool=pool)
-            host_local.copy_(packed, non_blocking=True)
+            r = resident(state["S"]).submit(d_frames)      # the product call: pipeline + async D2H of the packed result, in flight
+            if r is not None:
+                state["last"] = r[1]
             return
         # N>1: the path's only exchange step -- ONE fused all-gather of the packed corner lists, on the side stream:
         # step i's gather (+ rank 0's D2H of all lists) overlaps step i+1's convolutions; slots are double-buffered
         og.retire(i - og.depth)                         # host-side completion of the step that used this slot (gloo only)
-        out = og.acquire(i)
-        infer_batch_device(d_frames, 16, dc, rn, out=out, pool=pool)
-        og.launch(i)
+        with torch.cuda.stream(cs[i % state["S"]]):
+            out = og.acquire(i)
+            infer_batch_device(d_frames, 16, dc, rn, out=out, pool=pool)
+            og.launch(i)
 
     def fence():
         if og is not None:
             og.drain()
+        else:
+            for rs in rs_of.values():
+                for r in rs.flush():
+                    state["last"] = r[1]
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
@@ -240,6 +270,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         fence()
         if profile:
             L.dcx_profile_enable(1)      # restart the record list: the dominant-kernel choice uses the W warm-up steps only
+    for _ in range(max(0, S - warmup)):      # set-up, not warm-up: every stream's scratch buffers exist before anything is timed
+        step()
     for _ in range(warmup):
         step()
     fence()
@@ -249,23 +281,31 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         L.dcx_profile_enable(0)
         if warm:
             dom_id = max(warm.items(), key=lambda kv: kv[1][1])[0]
-        L.dcx_profile_filter(dom_id)          # timed region: only the dominant kernel is bracketed, and only every 5th of its
-        L.dcx_profile_sample(5)               # launches (a hipEvent bracket idles the GPU for ~11 us: 45 us per step if all four of
-                                              # a step were; 5 is coprime with the 4 launches per step, so every layer is sampled)
-        L.dcx_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if cx.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_pass(n_steps):
+        """EXACTLY n_steps steps between two fences; with profiling only the dominant kernel is bracketed, and only every 5th of
+        its launches (a hipEvent bracket idles its stream for ~11 us: 45 us per step if all four of a step were; 5 is coprime with
+        the 4 launches per step, so every layer is sampled)."""
+        if profile:
+            L.dcx_profile_filter(dom_id)
+            L.dcx_profile_sample(5)
+            L.dcx_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if cx.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed_pass(steps)              # THE timed region: `value`
 
     # ---- what the timed steps produced (outside the timed region)
     if og is None:
-        local = host_local.numpy().copy()
+        local = state["last"]                         # packed corner lists of the LAST timed step (pinned host copy)
         per_rank = [local]
     else:
         last = og.result(state["i"] - 1)              # (world, n_i32) as gathered by the LAST timed step
@@ -273,6 +313,21 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         local = per_rank[rank]
     res_local, counts_local = unpack_results(local, B, pool, True)
     total_patches = float(min(int(counts_local.astype(np.int64).sum()), pool))
+
+    timed_hdr = None
+    if profile:
+        timed_hdr = fetch_profile(L, total_patches)      # the dominant kernel as sampled INSIDE the timed region
+        L.dcx_profile_enable(0)
+    elapsed_1s = None
+    if S > 1 and profile:
+        # Per-kernel durations only mean something when nothing else shares the GPU: the roofline block is taken from a second
+        # pass of the SAME K steps on ONE stream (its throughput is reported beside `value` as single_stream)
+        state["S"] = 1
+        for _ in range(2):
+            step()
+        fence()
+        elapsed_1s = timed_pass(steps)
+    el_roof = elapsed_1s if elapsed_1s is not None else elapsed
 
     roofline = None
     if profile:
@@ -329,6 +384,21 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                                               "launches_per_step": v[2] / extra_steps,
                                               "clock_ghz": round(v[3] / v[1], 3) if v[1] > 0 else None}
                                    for k, v in full.items()}}
+        if elapsed_1s is not None:
+            # S > 1: the block above is the single-stream pass; what the same kernel looked like INSIDE the timed region (its
+            # launches share the CUs with the other stream's, so they last longer although the step is faster) is kept beside it
+            roofline["measured_in"] = (f"a second pass of the same {steps} steps on ONE HIP stream right after the timed region "
+                                       f"(per-kernel durations are only meaningful when nothing else shares the GPU); "
+                                       f"the timed region itself keeps {S} batches in flight")
+            roofline["e2e_executed_frac_single_stream"] = round(conv_exec / extra_steps / (elapsed_1s / steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            if timed_hdr and dom_id in timed_hdr and timed_hdr[dom_id][1] > 0:
+                f2, m2, l2, c2 = timed_hdr[dom_id]
+                roofline["in_timed_region"] = {"launches": l2, "avg_launch_ms": round(m2 / l2, 4),
+                                               "frac": round(f2 * exec_scale / (m2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                               "shader_clock_ghz": round(c2 / m2, 3),
+                                               "note": f"{S} batches in flight: launches of different batches overlap"}
+        else:
+            roofline["measured_in"] = "the timed region (one HIP stream)"
     if rank != 0:
         return None
 
@@ -360,14 +430,17 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
             res_r = unpack_results(per_rank[r], B, pool, True)[0]
             n_r = max(2, n_check // 2) if r == world - 1 else 2
             for b in ([0, B - 1] if n_r == 2 else pick[:n_r]):
-                j = kept_all[r][b] if fixed_k else b
-                fr = W.synthetic_frames(frames_kind, FRAME_SEED + r * 100000 + j, 1, H, Wd)[0]     # frame b of rank r's batch
+                if fixed_k:
+                    fr = W.synthetic_frames(frames_kind, FRAME_SEED + r * 100000 + kept_all[r][b], 1, H, Wd)[0]   # frame b of rank r's batch
+                else:
+                    fr = frames[(b + r) % B]                                      # rank r runs rank 0's frames rotated by r
                 checks.append(((name, r, b), fr, res_r[b]))
     parity = parity_block(oracle, checks)
 
     out = {
         "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / steps, 4), "steps": steps,
         "warmup": warmup,
+        "batches_in_flight": S,
         "config": {"workload": WL.workload_label(B, H, Wd, world, fixed_k), "preset": name,
                    "batch_per_gpu": B, "global_batch": B * world, "height": H, "width": Wd,
                    "corner_pool_per_gpu": pool, "corner_pool_note": "no per-frame cap: every firing cell of every frame is refined, as in the reference; the pool is shared by the batch",
@@ -377,13 +450,18 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                    "distinct_ids_in_batch": len(ids_seen),
                    "weights": "numpy-seeded synthetic (seed 1234/1235), ids-head biases equalised per class (all ids fire), dust-bin bias calibrated to ~16 corners/frame"
                               + (f"; frames selected by the workload generator so that exactly {fixed_k} cells fire in each" if fixed_k else ""),
-                   "parallelism": f"frames sharded, 1 process/GPU x{world}" + (", RCCL all-gather of corner lists on a side stream" if world > 1 else ""),
+                   "parallelism": f"frames sharded, 1 process/GPU x{world}" + (", RCCL all-gather of corner lists on a side stream" if world > 1 else "")
+                                  + (f"; consecutive batches alternate between {S} HIP streams ({S} batches in flight per GPU)" if S > 1 else ""),
                    "algorithmic_gflop_per_frame": round(gflop_frame, 3),
                    # the layers AS WRITTEN / peak: > 1 is possible because the Winograd families execute 4/9 (1/4) of those MACs;
                    # the executed fraction of the whole step is roofline.e2e_executed_frac
                    "e2e_algorithmic_over_peak": round(fps * gflop_frame / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
         "parity": parity,
     }
+    if elapsed_1s is not None:
+        out["single_stream"] = {"value": round(world * B * steps / elapsed_1s, 2), "unit": "frames/s",
+                                "ms_per_step": round(1e3 * elapsed_1s / steps, 4), "steps": steps,
+                                "note": "the same steps on ONE HIP stream (one batch in flight): the pass the roofline block is measured in"}
     if dist_on:
         out["gather_overlapped"] = bool(og.overlapped)
     if roofline is not None:
@@ -395,14 +473,16 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
 
 
 def two_stream_pipelined(cx, steps=40, warmup=6):
-    """cfg2's workload with CONSECUTIVE batches alternating between two HIP streams (what deepcharuco_amd.stream.FrameStream
-    does with compute_streams=2): batch i+1's detector kernels fill the CUs that batch i's small RefineNet launches, launch
-    ramps and partial last rounds leave idle.  A serving-style throughput number; it is not `value` because overlapping
-    launches make per-kernel durations (the roofline block) meaningless."""
+    """cfg2's workload (the SAME 32 frames in every batch) with consecutive batches alternating between two HIP streams, i.e. two
+    batches in flight (stream.ResidentStream(compute_streams=2) does the same).  Reported beside the one-stream headline; with
+    equal work per batch it is within +-2 % of it -- the launches of one batch already keep every CU's two workgroup slots busy."""
     dev = cx.dev
     p = WL.PRESETS["cfg2"]
     B, H, Wd, kmax = p["batch"], p["height"], p["width"], p["kmax"]
-    frames = [W.synthetic_frames("board", FRAME_SEED + 500 * i, B, H, Wd) for i in range(2)]
+    # EQUAL work in both streams: the same frames (rounds 2-5 took a second seed for stream 1, whose frames fire 9.9 instead of 16.0
+    # cells each under weights calibrated on the first -- the "+6 ... +15 %" those rounds quoted was the lighter batch, not overlap)
+    f0 = W.synthetic_frames("board", FRAME_SEED, B, H, Wd)
+    frames = [f0, f0.copy()]
     sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames[0]).to(dev), dev, diverse_ids=True)
     sd_rn = W.synthetic_state_dict("refinenet", 1235)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
@@ -432,7 +512,7 @@ def two_stream_pipelined(cx, steps=40, warmup=6):
         res, cnt = unpack_results(host[k].numpy(), B, pool, True)
         checks += [(("pipelined", k, b), frames[k][b], res[b]) for b in sorted({0, B - 1, int(np.argmax(cnt))})]
     return {"value": round(B * steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
-            "mode": "bs=32 320x240 batches alternating between two HIP streams (two batches in flight)",
+            "mode": "bs=32 320x240 batches (the same frames, i.e. equal work) alternating between two HIP streams (two batches in flight)",
             "parity": parity_block(oracle, checks)}
 
 
@@ -525,6 +605,10 @@ def main():
     ap.add_argument("--kmax", type=int, default=None, help="AVERAGE corners per frame the corner pool of a batch is sized for (pool = batch * kmax; no per-frame cap)")
     ap.add_argument("--frames", default=None, choices=["board", "board4", "noise"])
     ap.add_argument("--fixed-k", type=int, default=None, help="select frames with exactly this many corners (cfg5: 16)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="batches in flight per GPU: consecutive steps alternate between this many HIP streams (stream.ResidentStream). "
+                         "Default 1: with EQUAL work in every batch a second stream gains nothing (-1 ... -4 %, "
+                         "profiles/experiments/r05_batches_in_flight_equal_work.txt); > 1 adds a single-stream pass for the roofline block")
     ap.add_argument("--parity-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -555,6 +639,7 @@ def main():
     cx.dev = dev = torch.device("cuda", local_rank % ndev)
     cx.dist = None
     cx.force_dist = bool(args.force_dist)
+    cx.streams = args.streams
     dist_on = world > 1 or cx.force_dist
     if dist_on:
         import torch.distributed as dist
@@ -624,7 +709,7 @@ def main():
     }
     if dist_on:
         line["ranks"] = cx.ranks_seen
-    for k_ in ("gather_overlapped", "roofline", "cpu_baseline"):
+    for k_ in ("batches_in_flight", "single_stream", "gather_overlapped", "roofline", "cpu_baseline"):
         if k_ in main_res:
             line[k_] = main_res[k_]
     if others:

@@ -45,11 +45,11 @@ class FrameStream:
         shape = (batch, height, width, 3) if self.bgr else (batch, height, width)
         with torch.cuda.device(self.dev):
             self.copy_stream = torch.cuda.Stream()
-            # compute_streams = 2: consecutive batches run the pipeline on alternating streams, so batch i+1's detector
-            # kernels fill the CUs that batch i's small RefineNet launches / ramps / partial last rounds leave idle: +7 ... +15 %
-            # frames/s at bs=32 WHEN THE FRAMES ARE ALREADY IN HBM (bench.py cfg2_two_batches_in_flight).  Fed over PCIe, as this
-            # class is, the gain does not materialise (10.3 k vs 10.2 k on one stream, tools/framestream_probe.py) -- the default
-            # stays 1; the pipeline scratch is per (model, stream)
+            # compute_streams = 2: consecutive batches run the pipeline on alternating streams.  It gains nothing: rounds 2-5 quoted
+            # "+7 ... +15 % when the frames are already in HBM", but that comparison gave the second stream lighter batches; with
+            # equal work two streams are 1-4 % SLOWER than one (profiles/experiments/r05_batches_in_flight_equal_work.txt): every
+            # conv launch already fills both workgroup slots of every CU.  The default stays 1; the option stays for callers whose
+            # batches are small enough to leave CUs empty.  The pipeline scratch is per (model, stream)
             self.compute = [torch.cuda.Stream() for _ in range(compute_streams)] if compute_streams > 1 else None
             self.pin_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(depth)]
             self.dev_in = [torch.empty(shape, dtype=torch.uint8, device=self.dev) for _ in range(depth)]
@@ -140,4 +140,105 @@ class FrameStream:
                 held = r
         if held is not None:
             yield self._resolve(held)
+        yield from self.flush()
+
+
+class ResidentStream:
+    """Pipelined caller for batches that are ALREADY in HBM (camera frames decoded on the GPU, a previous kernel's output, the
+    measured configuration of bench.py): ``depth`` batches are enqueued ahead of the host, on one HIP stream of their own or on
+    ``compute_streams`` alternating ones.
+
+    What it buys is a host that never blocks on the batch it just enqueued: ``submit`` returns at once, the packed corner lists
+    of a batch arrive in pinned memory while the next batches run, and unpacking them overlaps GPU work (bench.py's timed loop
+    is this class with ``raw=True``).  ``compute_streams`` > 1 puts consecutive batches on alternating HIP streams; frames are
+    independent (inference.py:32-70 keeps no cross-frame state), every batch keeps its own launch order and its own scratch
+    (the pipeline workspace is per (model, stream)), so the results are bit-identical to ``infer_batch`` either way
+    (tests/test_gpu_parity.py::test_resident_stream_*).  At bs=32 320x240 a second stream does NOT raise throughput (-1 ... -4 %
+    with equal work in every batch, profiles/experiments/r05_batches_in_flight_equal_work.txt: one batch's launches already
+    occupy both workgroup slots of every CU) -- the default is one; more only pays for batches too small to fill the chip.
+
+    ``depth`` output slots rotate (default ``compute_streams + 2``): ``submit`` blocks only on the batch submitted ``depth``
+    submissions earlier, so the GPU always has work queued while the host retires / unpacks an older batch.  ``submit(frames)``: ``frames`` = contiguous (n <= batch, H, W) gray or (n, H, W, 3) BGR uint8
+    tensor on the model's GPU, produced on the CURRENT stream (the compute stream waits for an event recorded there); the caller
+    must leave it untouched until that batch has been handed out.  Returns the ``(ticket, results)`` of the batch that had to be
+    retired to make room, or None.  ``raw=True``: results are the packed int32 host arrays (``unpack_results`` layout) instead of
+    per-frame key-point arrays -- no host work besides the event wait.  Overflow of a batch's corner pool (``batch * kmax``
+    corners for the whole batch, no per-frame cap) is handled as everywhere else: that batch is run once more with the pool the
+    first pass reported."""
+
+    def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 32, height: int = 240, width: int = 320,
+                 kmax: int = DEFAULT_KMAX, compute_streams: int = 1, depth: Optional[int] = None, bgr: bool = False,
+                 raw: bool = False):
+        det = deepc.model if hasattr(deepc, "model") else deepc
+        self.dev = det.device
+        self.dust_bin_ids, self.deepc, self.refinenet = dust_bin_ids, deepc, refinenet
+        self.batch, self.h, self.w, self.kmax = batch, height, width, kmax
+        self.pool = batch * kmax
+        self.bgr, self.raw = bool(bgr), bool(raw)
+        if compute_streams < 1:
+            raise ValueError("compute_streams must be >= 1")
+        self.depth = depth = compute_streams + 2 if depth is None else depth
+        if depth < compute_streams:
+            raise ValueError("depth must be >= compute_streams")
+        n_out = packed_len(batch, self.pool)
+        with torch.cuda.device(self.dev):
+            self.compute = [torch.cuda.Stream() for _ in range(compute_streams)]
+            self.dev_out = [torch.empty((n_out,), dtype=torch.int32, device=self.dev) for _ in range(depth)]
+            self.pin_out = [torch.empty((n_out,), dtype=torch.int32).pin_memory() for _ in range(depth)]
+            self.ev_in = [torch.cuda.Event() for _ in range(depth)]
+            self.ev_done = [torch.cuda.Event() for _ in range(depth)]
+        self._pending: List[Optional[Tuple[int, torch.Tensor]]] = [None] * depth     # (ticket, device frames)
+        self._ticket = 0
+
+    def _collect(self, slot: int):
+        ticket, frames = self._pending[slot]
+        self._pending[slot] = None
+        n = frames.shape[0]
+        self.ev_done[slot].synchronize()
+        packed = self.pin_out[slot].numpy()[:packed_len(n, self.pool)]
+        need = int(packed[:n].astype(np.int64).sum())
+        if need > self.pool:         # rare: the batch fired more cells than its pool holds -> exact re-run with the pool it asked for
+            warnings.warn(f"a batch produced {need} corners > pool={self.pool} (batch x kmax); re-running it with pool={need}")
+            with torch.cuda.device(self.dev):
+                packed = infer_batch_device(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need).cpu().numpy()
+            if self.raw:
+                return ticket, packed
+            return ticket, unpack_results(packed, n, need, self.refinenet is not None)[0]
+        if self.raw:
+            return ticket, packed.copy()
+        return ticket, unpack_results(packed, n, self.pool, self.refinenet is not None)[0]
+
+    def submit(self, frames: torch.Tensor):
+        want = (self.h, self.w, 3) if self.bgr else (self.h, self.w)
+        if (not isinstance(frames, torch.Tensor) or frames.device != self.dev or frames.dtype != torch.uint8
+                or not frames.is_contiguous() or tuple(frames.shape[1:]) != want or not (1 <= frames.shape[0] <= self.batch)):
+            raise ValueError(f"frames must be a contiguous (1 <= n <= batch, {', '.join(map(str, want))}) uint8 tensor on {self.dev}")
+        n = frames.shape[0]
+        slot = self._ticket % self.depth
+        retired = self._collect(slot) if self._pending[slot] is not None else None
+        n_out = packed_len(n, self.pool)
+        with torch.cuda.device(self.dev):
+            compute = self.compute[self._ticket % len(self.compute)]
+            self.ev_in[slot].record(torch.cuda.current_stream())     # whatever produced `frames` was enqueued on the caller's stream
+            with torch.cuda.stream(compute):
+                compute.wait_event(self.ev_in[slot])
+                infer_batch_device(frames, self.dust_bin_ids, self.deepc, self.refinenet, out=self.dev_out[slot][:n_out],
+                                   pool=self.pool)
+                self.pin_out[slot][:n_out].copy_(self.dev_out[slot][:n_out], non_blocking=True)
+                self.ev_done[slot].record(compute)
+        self._pending[slot] = (self._ticket, frames)
+        self._ticket += 1
+        return retired
+
+    def flush(self) -> Iterator[Tuple]:
+        order = sorted((p[0], s) for s, p in enumerate(self._pending) if p is not None)
+        for _, slot in order:
+            yield self._collect(slot)
+
+    def run(self, batches: Iterable[torch.Tensor]) -> Iterator[Tuple]:
+        """batches: iterable of device tensors -> (ticket, results) in submission order."""
+        for fr in batches:
+            r = self.submit(fr)
+            if r is not None:
+                yield r
         yield from self.flush()

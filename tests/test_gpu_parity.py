@@ -1593,3 +1593,70 @@ def test_tail_handoff_is_never_stale(dev):
             bad += got != want[k]
         torch.cuda.synchronize()
         assert bad == 0, f"bs={bs}: {bad} of 150 calls differ from the fresh-workspace result"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams,depth", [(1, None), (2, None), (3, 3), (2, 2)])
+def test_resident_stream_matches_infer_batch_and_the_oracle(dev, streams, depth):
+    """stream.ResidentStream (HBM-resident batches on alternating HIP streams, several batches in flight -- what bench.py times)
+    hands out, in order, exactly what infer_batch returns for the same frames, which is what the ORACLE's per-frame infer_image
+    returns: ragged last batch, more batches than slots, BGR and gray, the raw (packed) form."""
+    from deepcharuco_amd.inference import infer_batch, unpack_results
+    from deepcharuco_amd.stream import ResidentStream
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 7100, 30, 120, 160)
+    sd_dc = _calibrated(57, frames[:4])
+    sd_rn = W.synthetic_state_dict("refinenet", 58)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
+    ref = infer_batch(frames, 16, dc, rn)
+    chunks = [torch.from_numpy(frames[i:i + 4]).to(dev) for i in range(0, 30, 4)]       # 7 full batches + one of 2 frames
+    rs = ResidentStream(16, dc, rn, batch=4, height=120, width=160, kmax=64, compute_streams=streams, depth=depth)
+    out = list(rs.run(chunks))
+    assert [t for t, _ in out] == list(range(8))
+    flat = [a for _, res in out for a in res]
+    assert len(flat) == 30 and all(x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y) for x, y in zip(flat, ref))
+    assert sum(r.shape[0] for r in ref if r.ndim == 2) > 100
+    if streams == 2 and depth is None:
+        t_dc, t_rn = O.to_torch_state_dict(sd_dc), O.to_torch_state_dict(sd_rn)
+        exp = [O.infer_image(None, 16, t_dc, t_rn, gray=f) for f in frames[:12]]
+        assert all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, exp))
+        # the same stream object keeps working after a flush; raw form = the packed buffers of infer_batch_device
+        raw = ResidentStream(16, dc, rn, batch=4, height=120, width=160, kmax=64, compute_streams=2, raw=True)
+        packed = list(raw.run(chunks + chunks))
+        assert len(packed) == 16
+        for (t, pk), ch in zip(packed, chunks + chunks):
+            res = unpack_results(pk, ch.shape[0], 4 * 64, True)[0]
+            lo = (t % 8) * 4
+            assert all(np.array_equal(a, b) for a, b in zip(res, ref[lo:lo + ch.shape[0]]))
+        # BGR batches (colour conversion inside the first layer's load)
+        bgr = [torch.from_numpy(np.repeat(frames[i:i + 4][..., None], 3, axis=3)).to(dev) for i in range(0, 12, 4)]
+        rb = ResidentStream(16, dc, rn, batch=4, height=120, width=160, kmax=64, bgr=True)
+        fb = [a for _, res in rb.run(bgr) for a in res]
+        assert all(np.array_equal(a, b) for a, b in zip(fb, ref[:12]))
+        with pytest.raises(ValueError):
+            rs.submit(chunks[0].cpu())
+        with pytest.raises(ValueError):
+            rs.submit(chunks[0][:, :100])
+
+
+@pytest.mark.gpu
+def test_resident_stream_pool_overflow_reruns_that_batch(dev):
+    """A batch that fires more cells than its pool (batch x kmax) is run once more with the pool it asked for -- in the middle of
+    a pipelined sequence, without disturbing the batches around it."""
+    from deepcharuco_amd.inference import infer_batch
+    from deepcharuco_amd.stream import ResidentStream
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 4400, 12, 120, 160)
+    sd_dc = _calibrated(4401, frames[:6], target_per_frame=20)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 4402), dev))
+    ref = infer_batch(frames, 16, dc, rn, kmax=64)
+    per_batch = [sum(r.shape[0] for r in ref[i:i + 3] if r.ndim == 2) for i in range(0, 12, 3)]
+    kmax = max(1, min(per_batch) // 3)            # pool = 3 * kmax <= the emptiest batch's total: every batch overflows or just fits
+    assert max(per_batch) > 3 * kmax
+    rs = ResidentStream(16, dc, rn, batch=3, height=120, width=160, kmax=kmax, compute_streams=2)
+    with pytest.warns(UserWarning, match="re-running"):
+        out = list(rs.run([torch.from_numpy(frames[i:i + 3]).to(dev) for i in range(0, 12, 3)]))
+    flat = [a for _, res in out for a in res]
+    assert len(flat) == 12 and all(x is not None and x.shape == y.shape and np.array_equal(x, y) for x, y in zip(flat, ref))

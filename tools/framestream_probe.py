@@ -27,7 +27,9 @@ def fs_run(name, **kw):
 def plain(name, nstreams, h2d):
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
     pin = [torch.from_numpy(frames).pin_memory() for _ in range(nstreams)]
-    d = [torch.empty((B, 240, 320), dtype=torch.uint8, device=dev) for _ in range(nstreams)]
+    # every stream's device buffer holds the frames (until round 5 these were torch.empty(): with h2d = False the kernels ran on
+    # whatever the allocator handed out -- stream 1's batches had no corners at all, which is where "2 streams, no H2D: 11,855 fps" came from)
+    d = [torch.from_numpy(frames).to(dev) for _ in range(nstreams)]
     n = packed_len(B, B * 64)
     out = [torch.empty((n,), dtype=torch.int32, device=dev) for _ in range(nstreams)]
     host = [torch.empty((n,), dtype=torch.int32).pin_memory() for _ in range(nstreams)]
