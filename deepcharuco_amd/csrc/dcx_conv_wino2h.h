@@ -56,6 +56,22 @@
 #ifndef DCX_W2H_E_XFORM
 #define DCX_W2H_E_XFORM 14
 #endif
+// the same for the TB = 1 kernels (16-tile items: launches that cannot fill the chip -- one workgroup per CU, nothing hides a
+// latency, and the operands come from the MALL / HBM rather than a warm L2): weights further ahead, the raw tile later.
+// Measured on the reference's bs=1 protocol (tools/ab_bs1.sh, profiles/experiments/r05_bs1_small_launches.txt): 5 / 9 / 14 ->
+// 10 / 14 / 18: +1.5 ... +2.5 %; 8 ... 14 positions ahead and stores at 14 ... 20 are all within the noise of each other
+#ifndef DCX_W2H_DQ1
+#define DCX_W2H_DQ1 10
+#endif
+#ifndef DCX_W2H_DQB1
+#define DCX_W2H_DQB1 2
+#endif
+#ifndef DCX_W2H_E_STORE1
+#define DCX_W2H_E_STORE1 14
+#endif
+#ifndef DCX_W2H_E_XFORM1
+#define DCX_W2H_E_XFORM1 18
+#endif
 // The two workgroups of a CU take turns at wave priority: bit DCX_PRIO_FLIP of the 100 MHz real-time clock (12: every 41 us),
 // inverted for the second-dispatched half of the grid.  Without it the SIMD arbiter prefers the OLDER workgroup, which finishes
 // its items ~16 % earlier and leaves the other one alone at the end of the launch.  Measured at bs=32 (two runs each, same box):
@@ -63,6 +79,10 @@
 // phase kernel's three workgroups gained nothing.  Speed only -- no effect on the bits.
 #ifndef DCX_PRIO_FLIP
 #define DCX_PRIO_FLIP 12
+#endif
+// TB = 1 work items issue their MFMAs position-pair-wise (see the unit body); 0 = one position at a time (the A/B of round 5)
+#ifndef DCX_W2H_TB1_PAIRS
+#define DCX_W2H_TB1_PAIRS 1
 #endif
 
 template <int TH_, int TW_, bool POOL_, int G_ = 1, int TB_ = 2>
@@ -110,14 +130,15 @@ struct DcxWino2hCfg {
     static constexpr int VPLANE = CQC * 32;                // float4 per position: [cq][tile]
     static constexpr int LDS_FLOAT4 = 16 * VPLANE;         // one transformed buffer (32 KB)
     static constexpr size_t LDS_BYTES = (size_t)(2 * LDS_FLOAT4 + RAW_LDS) * 16 + 256;     // + output-transform table
-    static constexpr int DQ = DCX_W2H_DQ;                        // weights: positions ahead
-    static constexpr int DQB = DCX_W2H_DQB;                        // transformed activations: positions ahead
+    static constexpr int DQ = TB_ == 1 ? DCX_W2H_DQ1 : DCX_W2H_DQ;   // weights: positions ahead
+    static constexpr int DQB = TB_ == 1 ? DCX_W2H_DQB1 : DCX_W2H_DQB;   // transformed activations: positions ahead
     // staging schedule in events (two per position: 32 per unit, 128 matrix cycles apart)
     static constexpr int E_RAW_LOAD = 0;
-    static constexpr int E_RAW_STORE = DCX_W2H_E_STORE;
-    static constexpr int E_XFORM = DCX_W2H_E_XFORM;                   // mid barrier before this event; 12 transform events follow
+    static constexpr int E_RAW_STORE = TB_ == 1 ? DCX_W2H_E_STORE1 : DCX_W2H_E_STORE;
+    static constexpr int E_XFORM = TB_ == 1 ? DCX_W2H_E_XFORM1 : DCX_W2H_E_XFORM;   // mid barrier before this event; XF_EVENTS transform events follow
+    static constexpr int XF_EVENTS = TB_ == 1 ? 8 : 12;               // TB = 1: quarter-piece transform (see the kernel)
     static_assert(TH % 2 == 0 && TW % 2 == 0 && NTILES <= 16 * TB && NTILES > 8 * TB && (TB == 1 || TB == 2), "tile must hold 17..32 (TB = 1: 9..16) 2x2 tiles");
-    static_assert(ITER_R <= 5 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM + 12 <= 32, "staging does not fit the schedule");
+    static_assert(ITER_R <= 5 && E_RAW_STORE + ITER_R <= E_XFORM && E_XFORM + XF_EVENTS <= 32 && DQ <= 16, "staging does not fit the schedule");
     static_assert(G == 1 || (!POOL && TPI == 16), "grouped tiles: two plain 8x8 maps");
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups must fit a CU's LDS");
 };
@@ -214,21 +235,30 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         }
     }
     float4* sR = sB + 2 * LDSF;
-    // transform piece of this thread: half h (xi rows 2h, 2h + 1) of (cq, tile); tiles past the end redo the last tile
+    // transform piece of this thread.  TB = 2 (17..32 tiles): half h (xi rows 2h, 2h + 1) of (cq, tile); tiles past the end redo the
+    // last tile.  TB = 1 (9..16 tiles): a QUARTER -- ONE xi row of (cq, tile), the row = the wave -- so that the 256 threads share
+    // the 4 x 16 x 4 rows evenly instead of half of them repeating tile 15: 8 ds_read_b128, 16 packed ops, 4 ds_write_b128 per
+    // thread and unit where the half-piece form takes 12 / 32 / 8 (the same fp32 operations on the same values: same bits).
+    constexpr bool QP = C::TB == 1;
     const int x_h = __builtin_amdgcn_readfirstlane(tid >> 7);          // wave-uniform: waves 0, 1 -> xi 0, 1; waves 2, 3 -> xi 2, 3
-    const int x_cq = (tid >> 5) & 3;
-    const int x_tile = min(tid & 31, C::NTILES - 1);
+    const int x_r = __builtin_amdgcn_readfirstlane(tid >> 6);          // QP: the wave's xi row
+    const int x_cq = QP ? (tid >> 4) & 3 : (tid >> 5) & 3;
+    const int x_tile = min(QP ? (tid & 15) : (tid & 31), C::NTILES - 1);
     const int x_img = x_tile / C::TPI, x_t = x_tile - x_img * C::TPI;
     const int x_ty = x_t / TX, x_tx = x_t - x_ty * TX;
     // rows of the half-piece, branch-free: first xi = row A - row B, second xi = row B + sgn * row C
     //   h = 0: xi 0 = d0 - d2 (A = 0, B = 2), xi 1 = d1 + d2 (C = 1, sgn = +1);  h = 1: xi 2 = d2 - d1 (A = 2, B = 1), xi 3 = d1 - d3 (C = 3, sgn = -1)
-    const int x_ia = x_h ? 2 : 0, x_ib = x_h ? 1 : 2, x_ic = x_h ? 3 : 1;
-    // raw slots of the window's left pixel (column 2 tx, always even) in the three rows this half needs
+    // rows of the quarter-piece: xi = row A + sgn * row B:  xi 0 = d0 - d2, xi 1 = d1 + d2, xi 2 = d2 - d1, xi 3 = d1 - d3
+    const int x_ia = QP ? (x_r == 0 ? 0 : x_r == 2 ? 2 : 1) : (x_h ? 2 : 0);
+    const int x_ib = QP ? (x_r == 2 ? 1 : x_r == 3 ? 3 : 2) : (x_h ? 1 : 2);
+    const int x_ic = x_h ? 3 : 1;
+    // raw slots of the window's left pixel (column 2 tx, always even) in the rows this piece needs
     const int x_ra = C::raw_slot(x_img, x_cq, 2 * x_ty + x_ia, 2 * x_tx), x_rb = C::raw_slot(x_img, x_cq, 2 * x_ty + x_ib, 2 * x_tx),
               x_rc = C::raw_slot(x_img, x_cq, 2 * x_ty + x_ic, 2 * x_tx);
-    const float x_sg = x_h ? -1.f : 1.f;
+    const float x_sg = QP ? (x_r == 1 ? 1.f : -1.f) : (x_h ? -1.f : 1.f);
     const dcx_f32x2 x_sgn = {x_sg, x_sg};
-    const int x_dst = (8 * x_h) * VPLANE + x_cq * 32 + x_tile;         // + local position * VPLANE
+    const int x_dst = QP ? (4 * x_r) * VPLANE + x_cq * 32 + x_tile
+                         : (8 * x_h) * VPLANE + x_cq * 32 + x_tile;         // + local position * VPLANE
     auto unit_rsrc = [&](const DcxItem& it, int c) {
         const long tile_off = (long)(((it.ty * C::TH) >> a.ups) - a.pad) * a.win + (((it.tx * C::TW) >> a.ups) - a.pad);
         const float* base = a.in + (((size_t)it.n * C::G * a.in_cq_total + a.in_cq_off + (size_t)c * CQC) * (size_t)a.hin * a.win
@@ -256,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     //   event 0: read the two rows of the first xi (8 ds_read_b128)      event 1: read the third row
     //   event 3 + ms (ms = 0..7, local position = 4 * (xi - 2h) + nu): at nu == 0 form t (4 float4 ops), then the position
     //   (1 float4 op); its LDS write goes out one event later           event 11: last write
+    // Quarter-piece (TB = 1): event 0 reads its two rows, events 3 .. 6 form the row's four positions, the last write is event 7.
     float4 xa[4], xb[4], xc[4], xt[4], xv;
     auto fma4s = [&](const float4& x, const float4& y) {      // y + sgn * x as two v_pk_fma_f32 (sgn = +-1: exactly y +- x)
         const dcx_f32x2 lo = __builtin_elementwise_fma(dcx_f32x2{x.x, x.y}, x_sgn, dcx_f32x2{y.x, y.y});
@@ -263,6 +294,21 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         return make_float4(lo.x, lo.y, hi.x, hi.y);
     };
     auto xform_event = [&](float4* vbuf, int x) {
+        if (QP) {
+            if (x == 0) {
+#pragma unroll
+                for (int cidx = 0; cidx < 4; ++cidx) { xa[cidx] = sR[x_ra + C::col_step(cidx)]; xb[cidx] = sR[x_rb + C::col_step(cidx)]; }
+            } else if (x >= 3 && x <= 7) {
+                const int nu = x - 3;
+                if (nu > 0) vbuf[x_dst + (nu - 1) * VPLANE] = xv;
+                if (nu == 0) {
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx) xt[cidx] = fma4s(xb[cidx], xa[cidx]);      // row A + sgn * row B
+                }
+                if (nu < 4) xv = nu == 0 ? sub4(xt[0], xt[2]) : nu == 1 ? add4(xt[1], xt[2]) : nu == 2 ? sub4(xt[2], xt[1]) : sub4(xt[1], xt[3]);
+            }
+            return;
+        }
         if (x == 0) {
 #pragma unroll
             for (int cidx = 0; cidx < 4; ++cidx) { xa[cidx] = sR[x_ra + C::col_step(cidx)]; xb[cidx] = sR[x_rb + C::col_step(cidx)]; }
@@ -331,10 +377,12 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         }
         const int buf = u & 1;
 #if DCX_PRIO_FLIP > 0
-        {
+        if (C::TB == 2) {
             // the SIMD arbiter prefers the OLDER of a CU's two workgroups, which then finishes its items ~16 % earlier and leaves the
             // other one alone at the end: take turns instead -- priority follows a bit of the real-time clock,
-            // inverted for the second-dispatched half of the grid
+            // inverted for the second-dispatched half of the grid.  Not in the TB = 1 kernels: their launches are the ones that
+            // cannot fill the chip (bs=1, 16 patches: one workgroup per CU, nobody to take turns with), where the clock read and
+            // its s_waitcnt at the head of every unit are ~110 exposed cycles per 3,400-cycle unit (tools/unit_probe.py, PROBE_B=1).
             const unsigned rt = (unsigned)__builtin_amdgcn_s_memrealtime();     // (read one unit ahead of its use -- no s_waitcnt at the
                                                                                  //  unit head -- measured in round 5: within the noise)
             const bool hi = (((rt >> DCX_PRIO_FLIP) & 1u) != 0u) != (blockIdx.x >= (gridDim.x >> 1));
@@ -371,15 +419,24 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                 roff[k] = inb ? r_rel[k] : 0x80000000u;
             }
         }
-        // one position = 4 TB MFMAs (tile blocks alternating, j = 0..3) in two slots of 2 TB; each slot is preceded by one
-        // staging event; slot 0 also fetches the operands of position p + DQ / p + DQB
+        // one position = 4 TB MFMAs (j = 0..3) in two slots of 2 TB; each slot is preceded by one staging event; the slot that
+        // opens a position also fetches the operands of position p + DQ / p + DQB.
+        // TB = 2: a slot's MFMAs alternate between the two tile blocks, so an accumulator is touched every other MFMA.
+        // TB = 1: positions are taken in PAIRS -- slot s of a pair issues MFMA j = s of BOTH positions -- for the same reason:
+        //   v_mfma_f32_16x16x4_f32 issues every 32 cycles but a dependent one (same accumulator) only after 40
+        //   (MI355X_MICROARCH.md), and with one workgroup per CU (bs=1, 16 patches: every TB = 1 launch) nothing else fills the
+        //   8-cycle bubble.  Round 5 until this change issued j = 0..3 of one position back to back: 2,560 instead of 2,048
+        //   matrix cycles per unit.  The order of the MFMAs on ONE accumulator is unchanged, so the bits are.
+        constexpr int PG = (TB == 1 && DCX_W2H_TB1_PAIRS) ? 2 : 1;       // positions per group
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            if (p * 2 == C::E_XFORM) __syncthreads();       // the raw tile of the next unit is complete in sR
+        for (int pg = 0; pg < 16; pg += PG) {
 #pragma unroll
-            for (int slot = 0; slot < 2; ++slot) {
+            for (int slot = 0; slot < 2 * PG; ++slot) {
+                const int e = pg * 2 + slot;                // staging event 0 .. 31
+                if (e == C::E_XFORM) __syncthreads();       // the raw tile of the next unit is complete in sR
                 __builtin_amdgcn_sched_barrier(0);
-                if (slot == 0) {
+                if ((slot & 1) == 0) {
+                    const int p = pg + (slot >> 1);
                     const int q = p + DQ, qb2 = p + DQB;
                     if (q < 16) aq[q] = load_a(wb_cur, q);
                     else aq[q] = load_a(wb_nxt, q - 16);
@@ -389,21 +446,34 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
                     }
                 }
                 {
-                    const int e = p * 2 + slot;          // staging event 0 .. 31
                     if (e >= C::E_RAW_LOAD && e < C::E_RAW_LOAD + ITER_R) rv[e - C::E_RAW_LOAD] = stage_fetch(rs_n, roff[e - C::E_RAW_LOAD]);
                     if (e >= C::E_RAW_STORE && e < C::E_RAW_STORE + ITER_R) sR[r_slot[e - C::E_RAW_STORE]] = rv[e - C::E_RAW_STORE];
-                    if (e >= C::E_XFORM && e < C::E_XFORM + 12) xform_event(vnext, e - C::E_XFORM);
+                    if (e >= C::E_XFORM && e < C::E_XFORM + C::XF_EVENTS) xform_event(vnext, e - C::E_XFORM);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                {
+                // (hazards: see the header comment -- operands come from loads hipcc waits for; VALU-written candidates only
+                //  at the very start of a unit -> 2 wait states ahead of the first MFMA)
+                if (e == 0) asm volatile("s_nop 1");
+                if (PG == 2) {
+                    const int j = slot;
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi) {
+                        const int p = pg + pi;
+                        const float4 aa = aq[p], bb = bq[p][0];
+                        const float av = j == 0 ? aa.x : j == 1 ? aa.y : j == 2 ? aa.z : aa.w;
+                        const float bv = j == 0 ? bb.x : j == 1 ? bb.y : j == 2 ? bb.z : bb.w;
+                        if (ZERO && j == 0)             // first touch of this accumulator in this work item: C = 0
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[p][0]) : "v"(av), "v"(bv));
+                        else
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][0]) : "v"(av), "v"(bv));
+                    }
+                } else {
+                    const int p = pg;
                     const float4 aa = aq[p];
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * slot + jj;
                         const float av = j == 0 ? aa.x : j == 1 ? aa.y : j == 2 ? aa.z : aa.w;
-                        // (hazards: see the header comment -- operands come from loads hipcc waits for; VALU-written candidates only
-                        //  at the very start of a unit -> 2 wait states ahead of the first MFMA)
-                        if (p == 0 && j == 0) asm volatile("s_nop 1");
 #pragma unroll
                         for (int tb = 0; tb < TB; ++tb) {
                             const float4 bb = bq[p][tb];
