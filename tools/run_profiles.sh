@@ -23,6 +23,8 @@ if [ "$MODE" = collect ]; then
     timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE \
         -d "$OUT/prof_r${R}_lds" -o lds -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_lds.log" 2>&1
     # FETCH_SIZE calibration on known byte counts (tools/ubench/fetch_calib.hip) and the flat-walk A/B of the item order
+    # (the binary is git-ignored: a fresh checkout has none -- build it here rather than lose the calibration pass)
+    [ -x "$ROOT/tools/ubench/fetch_calib" ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 "$ROOT/tools/ubench/fetch_calib.hip" -o "$ROOT/tools/ubench/fetch_calib"
     timeout 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_calib" -o calib -- $ROOT/tools/ubench/fetch_calib > "$OUT/calib.log" 2>&1
     DCX_XCD_WALK=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_r${R}_fetch_flat" -o fetch -- $B --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_fetch_flat.log" 2>&1
     # the other single-GPU configs: per-kernel times (their roofline blocks are in bench.log's other_configs)
