@@ -1240,6 +1240,14 @@ def test_bench_script_emits_parity_block_and_exit_code(dev):
     # 3 frames + the busiest frame of the timed batch
     assert d["parity"]["frames_checked"] in (3, 4) and d["parity"]["mismatched_frames"] == 0 and d["parity"]["corners"] > 0
     assert "BASELINE configs[1]" in d["config"]["workload"] and d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma"
+    # one batch in flight by default; the roofline block is measured inside the timed region
+    assert d["batches_in_flight"] == 1 and "single_stream" not in d and "timed region" in d["roofline"]["measured_in"]
+    # --streams 2: the timed region keeps two batches in flight, the roofline block comes from a one-stream pass of the same steps
+    out = subprocess.run(cmd + ["--streams", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d2 = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d2["batches_in_flight"] == 2 and d2["single_stream"]["value"] > 0 and d2["parity"]["mismatched_frames"] == 0
+    assert "ONE HIP stream" in d2["roofline"]["measured_in"] and d2["roofline"]["in_timed_region"]["launches"] > 0
     out = subprocess.run(cmd + ["--batch", "5", "--height", "120", "--width", "160"], env=env, capture_output=True, text=True, timeout=600)
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert out.returncode == 0 and "not a BASELINE config" in d["config"]["workload"]
