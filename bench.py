@@ -714,6 +714,10 @@ def main():
             line[k_] = main_res[k_]
     if others:
         line["other_configs"] = others
+    try:
+        C.CDLL(None).fflush(None)      # RCCL's version banner sits in the C stdout buffer until exit: flush it now, so that the JSON
+    except Exception:                  # line is the LAST line of stdout (a driver that reads the last line must find it)
+        pass
     print(json.dumps(line), flush=True)
     bad = main_res["parity"]["mismatched_frames"] + sum(v.get("parity", {}).get("mismatched_frames", 0) for v in others.values())
     if dist_on:
