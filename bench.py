@@ -311,6 +311,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         last = og.result(state["i"] - 1)              # (world, n_i32) as gathered by the LAST timed step
         per_rank = [last[r] for r in range(world)]
         local = per_rank[rank]
+    if og is None and len(local) != n_i32:            # the last batch overflowed its pool and was re-run with the pool it asked for
+        pool = (len(local) - 2 * B) // 6
     res_local, counts_local = unpack_results(local, B, pool, True)
     total_patches = float(min(int(counts_local.astype(np.int64).sum()), pool))
 

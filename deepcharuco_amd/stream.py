@@ -162,7 +162,8 @@ class ResidentStream:
     tensor on the model's GPU, produced on the CURRENT stream (the compute stream waits for an event recorded there); the caller
     must leave it untouched until that batch has been handed out.  Returns the ``(ticket, results)`` of the batch that had to be
     retired to make room, or None.  ``raw=True``: results are the packed int32 host arrays (``unpack_results`` layout) instead of
-    per-frame key-point arrays -- no host work besides the event wait.  Overflow of a batch's corner pool (``batch * kmax``
+    per-frame key-point arrays -- no host work besides the event wait (a batch that had to be re-run comes back laid out for
+    ``pool = sum(counts)``, which the buffer's own first ``n`` words give).  Overflow of a batch's corner pool (``batch * kmax``
     corners for the whole batch, no per-frame cap) is handled as everywhere else: that batch is run once more with the pool the
     first pass reported."""
 
