@@ -229,7 +229,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
 
     def resident(n_streams):
         if n_streams not in rs_of:
-            rs_of[n_streams] = ResidentStream(16, dc, rn, batch=B, height=H, width=Wd, kmax=kmax, compute_streams=n_streams, raw=True)
+            rs_of[n_streams] = ResidentStream(16, dc, rn, batch=B, height=H, width=Wd, kmax=kmax, compute_streams=n_streams, raw=True,
+                                              timing=True)
         return rs_of[n_streams]
 
     def step():
@@ -270,6 +271,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         fence()
         if profile:
             L.dcx_profile_enable(1)      # restart the record list: the dominant-kernel choice uses the W warm-up steps only
+    for _ in range(int(getattr(cx, "preroll", 0))):      # experiment knob (--preroll): untimed steps ahead of the W warm-up steps
+        step()
     for _ in range(max(0, S - warmup)):      # set-up, not warm-up: every stream's scratch buffers exist before anything is timed
         step()
     for _ in range(warmup):
@@ -279,6 +282,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     if profile:
         warm = fetch_profile(L, 16.0 * B)
         L.dcx_profile_enable(0)
+        warm = {k: a for k, a in warm.items() if k < 100}       # the convolution families (ids >= 100: conv1a, tail, finalize brackets)
         if warm:
             dom_id = max(warm.items(), key=lambda kv: kv[1][1])[0]
 
@@ -290,9 +294,13 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
             L.dcx_profile_filter(dom_id)
             L.dcx_profile_sample(5)
             L.dcx_profile_enable(1)
+        for rs in rs_of.values():
+            rs.reset_stats()
+        state["host_step_s"] = 0.0
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step()
+        state["host_step_s"] = time.perf_counter() - t0          # host time until the last step is enqueued (before the drain)
         fence()
         el = time.perf_counter() - t0
         if dist_on:
@@ -302,6 +310,13 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         return el
 
     elapsed = timed_pass(steps)              # THE timed region: `value`
+    # host / per-batch GPU timers of the timed region (N = 1: stream.ResidentStream keeps them)
+    rs_stats = None
+    if og is None:
+        rs = rs_of[state["S"]]
+        g = np.asarray(rs.gpu_ms, dtype=np.float64)
+        rs_stats = {"gpu_ms": g, "host_enqueue_s": rs.host_enqueue_s, "host_wait_s": rs.host_wait_s,
+                    "host_loop_s": state["host_step_s"]}
 
     # ---- what the timed steps produced (outside the timed region)
     if og is None:
@@ -349,6 +364,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
             dom_id = max(timed.items(), key=lambda kv: kv[1][1])[0]
         flop, msum, launches, clk = timed[dom_id]
         achieved = flop / (msum * 1e-3) / 1e12
+        misc = {k: a for k, a in full.items() if k >= 100}      # conv1a of both nets, tail, finalize (dcx_prof_begin ids)
+        full = {k: a for k, a in full.items() if k < 100}       # the convolution families
         conv_ms = sum(a[1] for a in full.values())
         conv_flop = sum(a[0] for a in full.values())
         # The Winograd families execute only part of a layer's ALGORITHMIC multiply-adds on the matrix cores (2-D F(2x2,3x3):
@@ -386,6 +403,38 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                                               "launches_per_step": v[2] / extra_steps,
                                               "clock_ghz": round(v[3] / v[1], 3) if v[1] > 0 else None}
                                    for k, v in full.items()}}
+        # ---- where a step's time goes.  Kernel durations: the 3 fully bracketed steps; wall / host: the timed region
+        ms_step = 1e3 * el_roof / steps
+        nonconv_ms = sum(a[1] for a in misc.values()) / extra_steps
+        brk = {"ms_per_step": round(ms_step, 4),
+               "conv_kernels_ms": round(conv_ms / extra_steps, 4),
+               "non_conv_kernels_ms": round(nonconv_ms, 4),
+               "non_conv_kernels": {kname(k): round(a[1] / extra_steps, 4) for k, a in sorted(misc.items())},
+               # what is left of a step's wall time: launch gaps between the 22 kernels, the D2H copy of the packed result, event waits
+               "gaps_and_d2h_ms": round(ms_step - conv_ms / extra_steps - nonconv_ms, 4),
+               "kernel_launches_per_step": int(round((sum(a[2] for a in full.values()) + sum(a[2] for a in misc.values())) / extra_steps)),
+               "shader_clock_ghz": round(clk / msum, 3),
+               "source": f"kernel durations: hipEvent brackets around every launch of {extra_steps} extra steps after the timed region; "
+                         "ms_per_step / host timers / per-batch GPU times: the timed region itself"}
+        if rs_stats is not None and elapsed_1s is None and len(rs_stats["gpu_ms"]):
+            g = rs_stats["gpu_ms"]
+            brk.update({
+                # per batch: from the moment its stream reached it to the last byte of its result in pinned memory
+                "gpu_ms_per_batch": {"min": round(float(g.min()), 4), "median": round(float(np.median(g)), 4),
+                                     "max": round(float(g.max()), 4), "first": round(float(g[0]), 4), "n": int(g.size),
+                                     "all": [round(float(v), 3) for v in g[:64]]},
+                # wall time of a step during which the stream had NO batch to work on (the host did not enqueue fast enough)
+                "stream_starved_ms": round(ms_step - float(g.mean()), 4),
+                "host_enqueue_ms": round(1e3 * rs_stats["host_enqueue_s"] / steps, 4),
+                "host_wait_ms": round(1e3 * rs_stats["host_wait_s"] / steps, 4),
+                "host_loop_ms": round(1e3 * rs_stats["host_loop_s"] / steps, 4)})
+        roofline["step_conv_ms"] = brk["conv_kernels_ms"]
+        roofline["step_non_conv_ms"] = brk["non_conv_kernels_ms"]
+        roofline["step_gaps_and_d2h_ms"] = brk["gaps_and_d2h_ms"]
+        if "host_enqueue_ms" in brk:
+            roofline["step_host_enqueue_ms"] = brk["host_enqueue_ms"]
+            roofline["step_stream_starved_ms"] = brk["stream_starved_ms"]
+        state["breakdown"] = brk
         if elapsed_1s is not None:
             # S > 1: the block above is the single-stream pass; what the same kernel looked like INSIDE the timed region (its
             # launches share the CUs with the other stream's, so they last longer although the step is faster) is kept beside it
@@ -468,6 +517,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         out["gather_overlapped"] = bool(og.overlapped)
     if roofline is not None:
         out["roofline"] = roofline
+        out["step_breakdown"] = state.get("breakdown")
     if cpu is not None:
         out["cpu_baseline"] = cpu
     del dc, rn
@@ -520,26 +570,35 @@ def two_stream_pipelined(cx, steps=40, warmup=6):
 
 def bs1_reference_protocol(cx, n_iter=500):
     """The reference's own measurement (src/benchmark.py:37-53): ONE 320x240 BGR host image, 5 warm-up + n timed
-    infer_image calls (BGR->gray, H2D, both nets, D2H, sort inside every call), fps = n / elapsed."""
+    infer_image calls (BGR->gray, H2D, both nets, D2H, sort inside every call), fps = n / elapsed.  The image IS the
+    reference's (src/reference/samples_test/IMG_7412.png, benchmark.py:34-35), carried as data by the golden fixture
+    tests/golden/img7412_240x320.npz (written by oracle/make_golden.py from the reference's own infer_image); the weights are
+    that fixture's (synthetic seed 1234, dust-bin bias calibrated so that 16 cells fire on this photo), so the result of every
+    call is compared with what the REFERENCE returned, not only with the oracle."""
     dev = cx.dev
-    frames = W.synthetic_frames("board", FRAME_SEED, 32, 240, 320)
-    sd_dc = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames).to(dev), dev, diverse_ids=True)
-    sd_rn = W.synthetic_state_dict("refinenet", 1235)
+    fx = np.load(os.path.join(REPO, "tests", "golden", "img7412_240x320.npz"))
+    meta = json.loads(str(fx["meta"]))
+    sd_dc = W.synthetic_state_dict("detector", meta["wseed"], meta["n_ids"])
+    sd_dc["convDb.bias"] = fx["convDb_bias"].astype(np.float32).copy()
+    sd_rn = W.synthetic_state_dict("refinenet", meta["wseed"] + 1)
+    if W.state_dict_sha256(sd_dc, "detector", meta["n_ids"]) != str(fx["sha_dc"]):
+        raise SystemExit("bs1_reference_protocol: regenerated weights differ from the fixture's")
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
-    # ONE image, as in the reference's loop; the first frame of the batch on which exactly n_ids = 16 corners fire (a whole board)
-    counts = WL.frame_counts(torch.from_numpy(frames).to(dev), dc)
-    pick = int(np.argmin(np.abs(counts.astype(np.int64) - 16)))
-    bgr = np.ascontiguousarray(np.repeat(frames[pick][..., None], 3, axis=2))
+    bgr = np.ascontiguousarray(fx["bgr_image"])
     for _ in range(5):
         kp, _ = infer_image(bgr, 16, dc, rn, draw_pred=False, device="cuda")
     t0 = time.time()
     for _ in range(n_iter):
         kp, _ = infer_image(bgr, 16, dc, rn, draw_pred=False, device="cuda")
     el = time.time() - t0
-    oracle = Oracle(sd_dc, sd_rn)
-    par = parity_block(oracle, [(("bs1", 0, pick), frames[pick], kp)])
+    exp = fx["final_rn"]
+    same = kp.dtype == exp.dtype and kp.shape == exp.shape and np.array_equal(kp, exp)
+    par = {"frames_checked": 1, "corners": int(exp.shape[0]), "mismatched_frames": 0 if same else 1,
+           "against": "what the REFERENCE's infer_image returned for this image and these weights (tests/golden/img7412_240x320.npz): "
+                      "ids, cells and sub-pixel xy identical"}
     return {"value": round(n_iter / el, 1), "unit": "frames/s", "ms_per_call": round(1e3 * el / n_iter, 4), "iters": n_iter,
             "protocol": "src/benchmark.py:37-53: bs=1 infer_image loop from one BGR host image, 5 warm-up calls",
+            "image": "the reference's benchmark image IMG_7412.png (320x240 colour photo, benchmark.py:34-35)",
             "corners": int(kp.shape[0]) if kp.ndim == 2 else 0, "parity": par,
             "vs_reference_readme_200fps": round(n_iter / el / REFERENCE_README_FPS, 2)}
 
@@ -612,6 +671,7 @@ def main():
                          "Default 1: with EQUAL work in every batch a second stream gains nothing (-1 ... -4 %, "
                          "profiles/experiments/r05_batches_in_flight_equal_work.txt); > 1 adds a single-stream pass for the roofline block")
     ap.add_argument("--parity-frames", type=int, default=8)
+    ap.add_argument("--preroll", type=int, default=0, help="experiment: extra untimed steps ahead of the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs (the other BASELINE configs, bs=1 protocol)")
@@ -642,6 +702,7 @@ def main():
     cx.dist = None
     cx.force_dist = bool(args.force_dist)
     cx.streams = args.streams
+    cx.preroll = args.preroll
     dist_on = world > 1 or cx.force_dist
     if dist_on:
         import torch.distributed as dist
@@ -711,7 +772,7 @@ def main():
     }
     if dist_on:
         line["ranks"] = cx.ranks_seen
-    for k_ in ("batches_in_flight", "single_stream", "gather_overlapped", "roofline", "cpu_baseline"):
+    for k_ in ("batches_in_flight", "single_stream", "gather_overlapped", "step_breakdown", "roofline", "cpu_baseline"):
         if k_ in main_res:
             line[k_] = main_res[k_]
     if others:

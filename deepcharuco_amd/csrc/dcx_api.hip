@@ -379,6 +379,7 @@ int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame
     const int h = height, w = width;
     int rc;
     // conv1a + bn1a + relu (net.py:60)
+    const int pt0 = dcx_prof_begin(DCX_PROF_CONV1A, batch, s);
     if (d_frames_u8)
         rc = dcx_launch_conv1_u8(d_frames_u8, frame_stride, pitch, pix, batch, h, w, 1, det->first.w, det->first.bias,
                                  det->first.alpha, det->first.beta, buf0, nullptr, zero_words, n_zero, s);
@@ -386,6 +387,7 @@ int detector_run(const dcx_detector* det, const uint8_t* d_frames_u8, long frame
         rc = dcx_launch_conv1_f32(d_images_f32, (long)h * w, w, batch, h, w, 1, det->first.w, det->first.bias,
                                   det->first.alpha, det->first.beta, buf0, nullptr, s);
     if (rc) return rc;
+    if ((rc = dcx_prof_end(pt0, s))) return rc;
     // encoder (net.py:61-70): {layer, input divisor, pool}
     struct Step { int layer, div, pool; };
     static const Step steps[7] = {{0, 1, 1}, {1, 2, 0}, {2, 2, 1}, {3, 4, 0}, {4, 4, 1}, {5, 8, 0}, {6, 8, 0}};
@@ -512,12 +514,14 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* f
     const int p = max_patches;
     const int* lim = d_total;
     // conv1a (pad 0) 24 -> 22 (refinenet.py:56); in the pipeline fused with extract_patches (model_utils.py:19-36)
+    const int pt0 = dcx_prof_begin(DCX_PROF_PATCHES, p, s);
     int rc = fsrc != nullptr
         ? dcx_launch_conv1_patches_u8(fsrc->frames, fsrc->frame_stride, fsrc->pitch, fsrc->pix, fsrc->height, fsrc->width, d_table, d_total, p, n_hint,
                                       rf->first.w, rf->first.bias, rf->first.alpha, rf->first.beta, buf0, s)
         : dcx_launch_conv1_f32(d_patches, 576, 24, p, 24, 24, 0, rf->first.w, rf->first.bias, rf->first.alpha,
                                rf->first.beta, buf0, lim, s);
     if (rc) return rc;
+    if ((rc = dcx_prof_end(pt0, s))) return rc;
     // refinenet.py:57-78: {layer, input size, ups-on-read, pad, pool}
     struct Step { int layer, hin, ups, pad, pool; };
     static const Step steps[9] = {
@@ -554,8 +558,11 @@ int refiner_run(const dcx_refiner* rf, const float* d_patches, const FrameSrc* f
     // (finalising inside the head kernel -- per-patch tickets, the last work item reduces -- was built and measured in round 5: the
     //  device-scope fence ahead of the ticket drains the item's software pipeline, 0.359 -> 0.693 ms at bs=32;
     //  profiles/experiments/r05_fused_finalize.md)
-    return dcx_launch_refine_finalize((const float*)(ws + L.pval), (const int*)(ws + L.pidx), heat_tiles, 64, p, lim,
-                                      d_table, d_corners, d_xy, s);
+    const int pt1 = dcx_prof_begin(DCX_PROF_FINALIZE, p, s);
+    rc = dcx_launch_refine_finalize((const float*)(ws + L.pval), (const int*)(ws + L.pidx), heat_tiles, 64, p, lim,
+                                    d_table, d_corners, d_xy, s);
+    if (rc) return rc;
+    return dcx_prof_end(pt1, s);
 }
 }  // namespace
 
@@ -611,9 +618,11 @@ int infer_range(const dcx_detector* det, const dcx_refiner* rf, const uint8_t* d
         po.tickets = ctrl + 64; po.cursor = ctrl; po.counts = d_counts; po.starts = d_starts; po.rows = d_rows;
         po.table = rf ? table : nullptr; po.conf = d_conf; po.conf_cells = (float*)(ws + L.det + D.conf);
         po.wc = wc; po.pool = pool;
+        const int pt = dcx_prof_begin(DCX_PROF_TAIL, batch, s);
         rc = dcx_launch_tail(act, batch, hc * wc, det->head_loc.w, det->head_loc.bias, det->head_ids.w, det->head_ids.bias,
                              det->head_ids.cout_pad, det->n_ids + 1, dust_bin, codes, nullptr, nullptr, &po, s);
         if (rc) return rc;
+        if ((rc = dcx_prof_end(pt, s))) return rc;
     }
     if (timing && (rc = timing_mark(2, s))) return rc;
     if (rf == nullptr) return timing ? timing_mark(3, s) : 0;

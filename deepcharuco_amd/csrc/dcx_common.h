@@ -71,6 +71,12 @@ int dcx_conv_cout_pad(int cout);
 // ups: the layer reads its input through a x2 up-sampling (the phase variant then writes 4 slots per low-resolution tile).
 int dcx_conv_heat_tiles(int ho, int wo, int ups);
 
+// per-launch profiling of the pipeline's launches outside the convolution families (dcx_conv_mfma.hip keeps the record list;
+// bench.py's step_breakdown): kernel ids >= 100, bracketed by dcx_api.hip
+enum { DCX_PROF_CONV1A = 100, DCX_PROF_PATCHES = 101, DCX_PROF_TAIL = 102, DCX_PROF_FINALIZE = 103 };
+int dcx_prof_begin(int kernel_id, int n, hipStream_t s);   // -> token, -1 when not recording
+int dcx_prof_end(int token, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------
 // everything else (dcx_misc.hip)
 

@@ -205,7 +205,33 @@ extern "C" int dcx_profile_sample(int every) { g_prof_every = every > 1 ? every 
 extern "C" int dcx_profile_count(void) { return (int)g_recs.size(); }
 extern "C" const char* dcx_profile_kernel_name(int id) {
     const int n = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+    switch (id) {      // the pipeline's launches outside the convolution families (bracketed by dcx_api.hip: dcx_prof_begin / _end)
+        case DCX_PROF_CONV1A: return "dcx_conv1_kernel (detector conv1a)";
+        case DCX_PROF_PATCHES: return "dcx_conv1_patches_kernel (RefineNet conv1a + patch gather)";
+        case DCX_PROF_TAIL: return "dcx_tail_kernel (1x1 heads + arg-max + compaction)";
+        case DCX_PROF_FINALIZE: return "dcx_refine_finalize_kernel";
+        default: break;
+    }
     return id >= 0 && id < n ? kCfgs[id].name : "?";
+}
+
+// hipEvent bracket around one non-conv launch of the pipeline (same record list as the convolutions; flops = 0).  Only while
+// profiling is on and unfiltered (a filter selects one convolution instantiation).  -> token for dcx_prof_end, -1 = not recording
+int dcx_prof_begin(int kernel_id, int n, hipStream_t stream) {
+    if (!g_prof || g_prof_filter >= 0) return -1;
+    ProfRec r;
+    r.kernel_id = kernel_id; r.n = n; r.limited = 0; r.flops_per_image = 0.0;
+    r.e0 = prof_event();
+    r.e1 = prof_event();
+    r.slot = (int)g_recs.size();
+    if (!r.e0 || !r.e1 || hipEventRecord(r.e0, stream) != hipSuccess) return -1;
+    g_recs.push_back(r);
+    return r.slot;
+}
+int dcx_prof_end(int token, hipStream_t stream) {
+    if (token < 0 || token >= (int)g_recs.size()) return 0;
+    DCX_CHECK_HIP(hipEventRecord(g_recs[token].e1, stream));
+    return 0;
 }
 // raw probe words of record i (debug aid for kernel tuning; layout documented in dcx_conv_mfma.h)
 extern "C" int dcx_profile_probe_words(int record, unsigned long long* out64) {

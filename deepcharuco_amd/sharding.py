@@ -64,15 +64,21 @@ class OverlappedGather:
     and the host-side gloo all-gather is completed lazily in ``retire`` / ``result`` -- after the next step has been
     enqueued, so the GPU still overlaps it."""
 
-    def __init__(self, n_i32: int, device: torch.device, group=None, backend: str = "nccl", depth: int = 2):
+    def __init__(self, n_i32: int, device: torch.device, group=None, backend: str = "nccl", depth: int = 2, timing: bool = False):
+        """``timing=True``: a timing-enabled event pair on the side stream brackets every exchange (the all-gather + the D2H of the
+        gathered lists; gloo: the D2H of the local list); ``gather_ms`` collects the durations as slots are reused / read, so that a
+        multi-GPU run can say what the exchange step costs and whether it stayed under the next step's convolutions."""
         self.n, self.dev, self.group, self.backend, self.depth = n_i32, device, group, backend, depth
         self.world = dist.get_world_size(group)
         self.overlapped = True
+        self.timing = bool(timing)
+        self.gather_ms: List[float] = []
         with torch.cuda.device(device):
             self.side = torch.cuda.Stream()
             self.out = [torch.empty((n_i32,), dtype=torch.int32, device=device) for _ in range(depth)]
             self.ev_compute = [torch.cuda.Event() for _ in range(depth)]
-            self.ev_side = [torch.cuda.Event() for _ in range(depth)]
+            self.ev_side = [torch.cuda.Event(enable_timing=self.timing) for _ in range(depth)]
+            self.ev_g0 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)] if self.timing else None
             self.host = [torch.empty((self.world, n_i32), dtype=torch.int32).pin_memory() for _ in range(depth)]
             if backend == "nccl":
                 self.gathered = [torch.empty((self.world, n_i32), dtype=torch.int32, device=device) for _ in range(depth)]
@@ -80,6 +86,7 @@ class OverlappedGather:
                 self.host_local = [torch.empty((n_i32,), dtype=torch.int32).pin_memory() for _ in range(depth)]
         self._pending = [False] * depth          # gloo: D2H issued, host all-gather not yet done
         self._used = [False] * depth
+        self._timed = [False] * depth            # timing: an exchange of this slot has been bracketed and not yet harvested
 
     def warm_up(self, rounds: int = 64) -> None:
         """Run the exchange ``rounds`` times on the (still unused) buffers and wait for it.  RCCL / c10d finish initialising
@@ -100,15 +107,26 @@ class OverlappedGather:
         s = i % self.depth
         if self._used[s]:
             torch.cuda.current_stream(self.dev).wait_event(self.ev_side[s])
+            self._harvest(s)
         return self.out[s]
+
+    def _harvest(self, s: int) -> None:
+        """Duration of the slot's last exchange, if it has completed (never blocks: a slot still in flight is harvested later)."""
+        if self.timing and self._timed[s] and self.ev_side[s].query():
+            self.gather_ms.append(self.ev_g0[s].elapsed_time(self.ev_side[s]))
+            self._timed[s] = False
 
     def launch(self, i: int) -> None:
         """Call right after step i's kernels have been enqueued on the current (compute) stream."""
         s = i % self.depth
         compute = torch.cuda.current_stream(self.dev)
         self.ev_compute[s].record(compute)
+        self._harvest(s)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_compute[s])
+            if self.timing:
+                self.ev_g0[s].record(self.side)
+                self._timed[s] = True
             if self.backend == "nccl":
                 work = dist.all_gather_into_tensor(self.gathered[s].view(-1), self.out[s], group=self.group, async_op=True)
                 work.wait()                                   # the SIDE stream waits for RCCL's stream; the host does not
@@ -136,6 +154,8 @@ class OverlappedGather:
                 dist.all_gather_into_tensor(self.host[s].view(-1), self.host_local[s], group=self.group)
                 self._pending[s] = False
         self.side.synchronize()
+        for s in range(self.depth):
+            self._harvest(s)
 
     def result(self, i: int) -> np.ndarray:
         """(world, n) int32 host array of step i's gathered corner lists (blocks until they have arrived)."""
@@ -158,7 +178,9 @@ def unpack_gathered(gathered: np.ndarray, n_frames: int, world: int, pool: int, 
         rr, cc = unpack_results(gathered[r], batch_max, pool, refined)
         res.extend(rr[:hi - lo])
         counts_all.extend(cc[:hi - lo].tolist())
-        need = max(need, int(cc[:hi - lo].astype(np.int64).sum()))
+        # ALL batch_max counts of the rank: blank padding frames of a ragged shard (infer_batches_sharded runs them) take pool
+        # slots too, in whatever order the frames finished -- a pool that holds the real frames alone is not enough then
+        need = max(need, int(cc.astype(np.int64).sum()))
     return res, np.asarray(counts_all, np.int32), need
 
 
@@ -223,7 +245,9 @@ def infer_batches_sharded(batches, dust_bin_ids: int, deepc, refinenet=None, kma
 
     def finish(step, frames_j):
         res, _, need = unpack_gathered(og.result(step), frames_j.shape[0], world, pool, refinenet is not None)
-        if need > pool:       # every rank sees the same gathered counts, so every rank takes this branch
+        # every rank sees the same gathered buffers, so every rank takes this branch (the second condition cannot hold without the
+        # first -- a frame only comes back as None when its rank's pool overflowed -- and is kept as a guard)
+        if need > pool or any(r is None for r in res):
             res = infer_frames_sharded(frames_j, dust_bin_ids, deepc, refinenet, group=group, pool=need)
         return res
 

@@ -12,6 +12,7 @@ the next batches; ``run`` then yields ``(ticket, results, poses)``.
 """
 from __future__ import annotations
 
+import time
 import warnings
 from typing import Iterable, Iterator, List, Optional, Tuple
 
@@ -169,13 +170,17 @@ class ResidentStream:
 
     def __init__(self, dust_bin_ids: int, deepc, refinenet=None, batch: int = 32, height: int = 240, width: int = 320,
                  kmax: int = DEFAULT_KMAX, compute_streams: int = 1, depth: Optional[int] = None, bgr: bool = False,
-                 raw: bool = False):
+                 raw: bool = False, timing: bool = False):
+        """``timing=True``: every batch is bracketed by a timing-enabled event pair on its compute stream; ``gpu_ms`` then
+        holds, per retired batch, the time from the moment the stream reached the batch to its last byte in pinned memory
+        (bench.py's step_breakdown).  The host-side counters ``host_enqueue_s`` (time spent inside ``submit`` launching work) and
+        ``host_wait_s`` (time blocked on the oldest batch's completion event) are always kept."""
         det = deepc.model if hasattr(deepc, "model") else deepc
         self.dev = det.device
         self.dust_bin_ids, self.deepc, self.refinenet = dust_bin_ids, deepc, refinenet
         self.batch, self.h, self.w, self.kmax = batch, height, width, kmax
         self.pool = batch * kmax
-        self.bgr, self.raw = bool(bgr), bool(raw)
+        self.bgr, self.raw, self.timing = bool(bgr), bool(raw), bool(timing)
         if compute_streams < 1:
             raise ValueError("compute_streams must be >= 1")
         self.depth = depth = compute_streams + 2 if depth is None else depth
@@ -187,21 +192,46 @@ class ResidentStream:
             self.dev_out = [torch.empty((n_out,), dtype=torch.int32, device=self.dev) for _ in range(depth)]
             self.pin_out = [torch.empty((n_out,), dtype=torch.int32).pin_memory() for _ in range(depth)]
             self.ev_in = [torch.cuda.Event() for _ in range(depth)]
-            self.ev_done = [torch.cuda.Event() for _ in range(depth)]
-        self._pending: List[Optional[Tuple[int, torch.Tensor]]] = [None] * depth     # (ticket, device frames)
+            self.ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(depth)] if self.timing else None
+            self.ev_done = [torch.cuda.Event(enable_timing=self.timing) for _ in range(depth)]
+        self._pending: List[Optional[Tuple[int, torch.Tensor, torch.cuda.Stream]]] = [None] * depth     # (ticket, device frames, its stream)
         self._ticket = 0
+        self.gpu_ms: List[float] = []
+        self.host_enqueue_s = 0.0
+        self.host_wait_s = 0.0
+
+    def reset_stats(self) -> None:
+        self.gpu_ms = []
+        self.host_enqueue_s = self.host_wait_s = 0.0
 
     def _collect(self, slot: int):
-        ticket, frames = self._pending[slot]
+        ticket, frames, compute = self._pending[slot]
         self._pending[slot] = None
         n = frames.shape[0]
+        t0 = time.perf_counter()
         self.ev_done[slot].synchronize()
+        self.host_wait_s += time.perf_counter() - t0
+        if self.timing:
+            self.gpu_ms.append(self.ev_start[slot].elapsed_time(self.ev_done[slot]))
         packed = self.pin_out[slot].numpy()[:packed_len(n, self.pool)]
         need = int(packed[:n].astype(np.int64).sum())
-        if need > self.pool:         # rare: the batch fired more cells than its pool holds -> exact re-run with the pool it asked for
+        if need > self.pool:
+            # rare: the batch fired more cells than its pool holds -> exact re-run with the pool it asked for, on the batch's OWN
+            # compute stream (behind whatever was submitted after it: the caller's stream is not touched and not synchronised),
+            # handed out through pinned memory like every other batch; the host waits for that one event only
             warnings.warn(f"a batch produced {need} corners > pool={self.pool} (batch x kmax); re-running it with pool={need}")
+            n_big = packed_len(n, need)
             with torch.cuda.device(self.dev):
-                packed = infer_batch_device(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need).cpu().numpy()
+                host = torch.empty((n_big,), dtype=torch.int32).pin_memory()
+                done = torch.cuda.Event()
+                with torch.cuda.stream(compute):
+                    big = infer_batch_device(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need)
+                    host.copy_(big, non_blocking=True)
+                    done.record(compute)
+            t0 = time.perf_counter()
+            done.synchronize()
+            self.host_wait_s += time.perf_counter() - t0
+            packed = host.numpy()
             if self.raw:
                 return ticket, packed
             return ticket, unpack_results(packed, n, need, self.refinenet is not None)[0]
@@ -217,18 +247,22 @@ class ResidentStream:
         n = frames.shape[0]
         slot = self._ticket % self.depth
         retired = self._collect(slot) if self._pending[slot] is not None else None
+        t0 = time.perf_counter()
         n_out = packed_len(n, self.pool)
         with torch.cuda.device(self.dev):
             compute = self.compute[self._ticket % len(self.compute)]
             self.ev_in[slot].record(torch.cuda.current_stream())     # whatever produced `frames` was enqueued on the caller's stream
             with torch.cuda.stream(compute):
                 compute.wait_event(self.ev_in[slot])
+                if self.timing:
+                    self.ev_start[slot].record(compute)
                 infer_batch_device(frames, self.dust_bin_ids, self.deepc, self.refinenet, out=self.dev_out[slot][:n_out],
                                    pool=self.pool)
                 self.pin_out[slot][:n_out].copy_(self.dev_out[slot][:n_out], non_blocking=True)
                 self.ev_done[slot].record(compute)
-        self._pending[slot] = (self._ticket, frames)
+        self._pending[slot] = (self._ticket, frames, compute)
         self._ticket += 1
+        self.host_enqueue_s += time.perf_counter() - t0
         return retired
 
     def flush(self) -> Iterator[Tuple]:

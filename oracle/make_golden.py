@@ -196,7 +196,23 @@ CASES = [
     # ids head equalised per class on the reference's logits: >= 12 of the 16 ids fire on this one frame (the other fixtures'
     # random-init ids heads fire 1-3 distinct ids); full logits kept so the 17-way arg-max is checked on diverse winners
     dict(name="diverse_ids_240x320", wseed=7, kind="board", fseed=2, H=240, W=320, K=16, full=True, diverse=True),
+    # The reference's ONLY real input: the 320x240 colour photo its benchmark times (src/benchmark.py:34-35,
+    # src/reference/samples_test/IMG_7412.png), read with Pillow (RGB -> BGR = what cv2.imread returns), through the reference's
+    # infer_image with two synthetic weight sets (the published checkpoints are not in the mount).  The u8 image travels inside the
+    # fixture (data); its gray version is what the stubbed cv2.cvtColor (= the oracle's OpenCV-4.x fixed-point formula) produced.
+    dict(name="img7412_240x320", wseed=1234, kind="img7412", fseed=0, H=240, W=320, K=16, full=True),
+    dict(name="img7412_diverse_240x320", wseed=7, kind="img7412", fseed=0, H=240, W=320, K=16, full=False, diverse=True, min_ids=8),
 ]
+IMG7412 = "/root/reference/src/reference/samples_test/IMG_7412.png"
+
+
+def load_img7412():
+    """(240,320,3) uint8 BGR, as cv2.imread(SAMPLE_IMAGE) (benchmark.py:35) returns it: PNG decoding is lossless, so Pillow's RGB
+    planes reversed are the same bytes."""
+    from PIL import Image
+    rgb = np.asarray(Image.open(IMG7412).convert("RGB"))
+    assert rgb.shape == (240, 320, 3) and rgb.dtype == np.uint8
+    return np.ascontiguousarray(rgb[..., ::-1])
 N_IDS = 16
 
 
@@ -227,7 +243,14 @@ def main():
         sd_dc = W.synthetic_state_dict("detector", c["wseed"], N_IDS)
         sd_rn = W.synthetic_state_dict("refinenet", c["wseed"] + 1)
         dc, rn = ref_models(ref_net, ref_rn, sd_dc, sd_rn, N_IDS)
-        frame = W.synthetic_frames(c["kind"], c["fseed"], 1, c["H"], c["W"])[0]
+        photo = None
+        if c["kind"] == "img7412":
+            photo = load_img7412()
+            import cv2 as cv2_stub_
+            frame = cv2_stub_.cvtColor(photo, cv2_stub_.COLOR_BGR2GRAY)     # what inference.py:40 computes (stub = oracle formula)
+            assert not np.array_equal(frame, photo[..., 1])                  # a real colour image, not gray x3
+        else:
+            frame = W.synthetic_frames(c["kind"], c["fseed"], 1, c["H"], c["W"])[0]
         if c.get("diverse"):
             equalise_ids(dc, sd_dc, frame, N_IDS, c["K"])
         dust_bias = calibrate_dustbin(dc, sd_dc, frame, N_IDS, c["K"])
@@ -241,12 +264,12 @@ def main():
         kpts, ids_found = ref_mu.pred_to_keypoints(loc, ids, N_IDS)
         assert kpts.shape[0] == c["K"], (name, kpts.shape)
         if c.get("diverse"):
-            assert len(set(ids_found.tolist())) >= 12, (name, ids_found)
+            assert len(set(ids_found.tolist())) >= c.get("min_ids", 12), (name, ids_found)
         patches = ref_mu.extract_patches(x, kpts)
         with torch.no_grad():
             heat = rn(patches[:, None])
         corners_og, corners = rn.infer_patches(patches, kpts)
-        bgr = np.repeat(frame[..., None], 3, axis=2)
+        bgr = photo if photo is not None else np.repeat(frame[..., None], 3, axis=2)
         final_rn, img_out = ref_inf.infer_image(bgr, N_IDS, dc, rn, draw_pred=False, device="cpu")
         assert img_out is bgr
         final_norn, _ = ref_inf.infer_image(bgr, N_IDS, dc, None, draw_pred=False, device="cpu")
@@ -300,6 +323,8 @@ def main():
             heat_first2=heat[:2, 0].numpy(),
             final_rn=final_rn, final_norn=final_norn,
         )
+        if photo is not None:
+            fx["bgr_image"] = photo
         if c["full"]:
             fx["loc_logits"] = loc[0].numpy()
             fx["ids_logits"] = ids[0].numpy()

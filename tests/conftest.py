@@ -10,7 +10,9 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
-CASES = ["tiny_noise_64x96", "noise_240x320", "board_240x320", "board_480x640", "board4_960x1280", "diverse_ids_240x320"]
+CASES = ["tiny_noise_64x96", "noise_240x320", "board_240x320", "board_480x640", "board4_960x1280", "diverse_ids_240x320",
+         # the reference's only real input (src/benchmark.py:34-35: IMG_7412.png, a 320x240 colour photo) under two weight sets
+         "img7412_240x320", "img7412_diverse_240x320"]
 
 
 def pytest_configure(config):
@@ -43,7 +45,13 @@ class GoldenCase:
             self.sd_dc["convDb.bias"] = self.fx["convDb_bias"].astype(np.float32).copy()
         self.sd_dc["convDb.bias"][m["n_ids"]] = self.fx["dust_bias"]
         self.sd_rn = W.synthetic_state_dict("refinenet", m["wseed"] + 1)
-        self.frame = W.synthetic_frames(m["kind"], m["fseed"], 1, m["H"], m["W"])[0]
+        self._bgr = None
+        if "bgr_image" in self.fx:            # a real colour image travels inside the fixture; gray = the 8-bit fixed-point formula
+            from deepcharuco_amd.imgproc import bgr2gray_fixed_point
+            self._bgr = np.ascontiguousarray(self.fx["bgr_image"])
+            self.frame = bgr2gray_fixed_point(self._bgr)
+        else:
+            self.frame = W.synthetic_frames(m["kind"], m["fseed"], 1, m["H"], m["W"])[0]
         assert W.state_dict_sha256(self.sd_dc, "detector", m["n_ids"]) == str(self.fx["sha_dc"]), \
             "regenerated detector weights differ from the ones the fixture was made with"
         assert W.state_dict_sha256(self.sd_rn, "refinenet") == str(self.fx["sha_rn"])
@@ -51,6 +59,8 @@ class GoldenCase:
 
     @property
     def bgr(self):
+        if self._bgr is not None:
+            return self._bgr
         return np.repeat(self.frame[..., None], 3, axis=2)
 
 

@@ -412,6 +412,89 @@ def test_infer_image_vs_golden(dev, golden):
         assert kp2.dtype == np.int64 and np.array_equal(kp2, fx["final_norn"])
 
 
+def test_stress_parity_slice(dev):
+    """A bounded slice of tools/stress_parity.py IN the driver-run suite: ~1,750 seeded frames at the four
+    resolutions 96x64 ... 640x480, ~22 weight sets, a third of the chunks with all 16 ids firing, every second chunk with the
+    dust-bin threshold within +-2e-4 of a cell's own margin.  Reference pass = the oracle, a chunk per batch, 8 threads; beside the
+    product path the oracle ITSELF at one thread is compared with that pass (the reference's own noise floor).  Hard gates:
+      * no loc / ids / heat-map arg-max and no fire / no-fire decision differs where the reference's own margin is >= 1e-5 (MARGIN),
+      * largest |HIP logit - oracle logit| <= LOGIT_ATOL (5e-5),
+      * frames differing end to end (ids + cells + sub-pixel xy) <= the oracle-at-1-thread column + 2.
+    Matches models/model_utils.py:72-77,111-122 (what an arg-max flip changes).  Counts go to gpurun_out/parity_report.json."""
+    import subprocess
+    import sys
+    import time
+    t0 = time.time()
+    workers = max(4, min(14, (os.cpu_count() or 8) // 8))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "stress_parity.py"), "1500", str(workers), "8", "--slice"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    with open(os.path.join(REPO, "gpurun_out", "stress_parity_slice.json")) as f:
+        out = json.load(f)
+    edges = [0.0, 1e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 1e-3]
+    first_gated = edges.index(MARGIN)                    # buckets [1e-5, 3e-5) and up
+    hip, o1 = out["results"]["hip_default"], out["results"]["oracle_1thr"]
+    rep = {"frames": out["frames"], "seconds": round(time.time() - t0, 1), "per_resolution": out["per_resolution"],
+           "reference_pass": out["reference_pass"], "firing_cells_per_id": out["firing_cells_per_id"], "margin_gate": MARGIN}
+    for name, col in (("hip_default", hip), ("oracle_1thr", o1)):
+        h = col["histogram"]
+        rep[name] = {"max_abs_logit_diff": col["max_abs_logit_diff"], "mean_abs_logit_diff": col["mean_abs_logit_diff"],
+                     "cells_decided_differently": col["cells_decided_differently"],
+                     "end_to_end": col["end_to_end"],
+                     **{k: {"decided": int(sum(h[k]["decided"])), "differs_total": int(sum(h[k]["differs"])),
+                            "differs_at_margin_ge_1e-5": int(sum(h[k]["differs"][first_gated:]))} for k in ("loc", "ids", "heat", "fire")}}
+    _report("stress_parity_slice", rep)
+    print("stress parity slice:", json.dumps(rep))
+    assert out["frames"] >= 1500 and len(out["per_resolution"]) == 4
+    assert min(out["firing_cells_per_id"]) > 0                                   # every id of the board fired somewhere
+    assert hip["end_to_end"]["frames"] >= 350 and hip["end_to_end"]["corners"] > 2000
+    for k in ("loc", "ids", "heat", "fire"):
+        assert rep["hip_default"][k]["differs_at_margin_ge_1e-5"] == 0, (k, rep["hip_default"][k])
+        assert rep["hip_default"][k]["decided"] > 0
+    assert hip["max_abs_logit_diff"] <= LOGIT_ATOL
+    assert hip["end_to_end"]["mismatched_frames"] <= o1["end_to_end"]["mismatched_frames"] + 2
+
+
+@pytest.mark.parametrize("name", ["img7412_240x320", "img7412_diverse_240x320"])
+def test_real_photo_img7412_colour_paths(dev, name):
+    """The reference's only real input -- the 320x240 colour photo its benchmark times (src/benchmark.py:34-35) -- against what the
+    REFERENCE's infer_image returned for it (tests/golden/img7412_*.npz, oracle/make_golden.py): through the batched BGR entry
+    (DCX_PIX_BGR8: the conversion of inference.py:40 inside conv1a's load and RefineNet's patch gather), through the host
+    conversion + gray entry, through infer_image (one hipGraph replay) and the resident-stream caller; a real photo's colour
+    content, dark smooth regions and ReLU sparsity instead of the seeded noise / procedural boards of every other fixture."""
+    from conftest import GoldenCase
+    from deepcharuco_amd import imgproc
+    from deepcharuco_amd.inference import infer_batch, infer_image
+    from deepcharuco_amd.stream import ResidentStream
+    case = GoldenCase(name)
+    fx = case.fx
+    bgr = case.bgr
+    assert bgr.shape == (240, 320, 3) and not np.array_equal(bgr[..., 0], bgr[..., 2])       # colour, not gray x3
+    assert int((O.bgr2gray(bgr, "opencv4") != O.bgr2gray(bgr, "legacy14")).sum()) > 0          # the two cv2 generations differ on it
+    dc, rn = _models(case, dev)
+    exp, exp_norn = fx["final_rn"], fx["final_norn"]
+    # (a) batched BGR entry: three copies of the photo in one batch, conversion on the device
+    res = infer_batch(np.stack([bgr, bgr, bgr]), case.n_ids, dc, rn)
+    for r in res:
+        assert r.dtype == np.float64 and np.array_equal(r, exp)
+    res = infer_batch(bgr[None], case.n_ids, dc, None)
+    assert res[0].dtype == np.int64 and np.array_equal(res[0], exp_norn)
+    # (b) host conversion (cv2 where it exists, else the fixed-point formula) + gray entry
+    gray = imgproc.bgr2gray(bgr)
+    if not imgproc._opencv():
+        assert np.array_equal(gray, case.frame)
+    assert np.array_equal(infer_batch(gray[None], case.n_ids, dc, rn)[0], exp)
+    # (c) the drop-in call and (d) the non-blocking caller for resident frames, BGR
+    kp, img = infer_image(bgr, case.n_ids, dc, rn, device="cuda")
+    assert img is bgr and np.array_equal(kp, exp)
+    rs = ResidentStream(case.n_ids, dc, rn, batch=2, height=240, width=320, bgr=True)
+    d = torch.from_numpy(np.stack([bgr, bgr])).to(dev)
+    out = [r for _, r in rs.run([d, d, d])]
+    assert len(out) == 3 and all(np.array_equal(f, exp) for r in out for f in r)
+    _report(f"real_photo/{name}", dict(corners=int(exp.shape[0]), distinct_ids=int(len(set(exp[:, 2].tolist()))),
+                                       opencv="present " + imgproc._opencv().__version__ if imgproc._opencv() else "absent (device fixed-point conversion)"))
+
+
 def test_fused_tail_on_diverse_ids_hundreds_of_cells(dev):
     """The fused detector tail (1x1 heads + 65-/17-way arg-max + dust-bin rule, csrc/dcx_tail.hip) on DIVERSE winners: the
     diverse-ids weight set with the dust-bin bias lowered so that hundreds of cells per frame fire with all 16 ids, four frames,
@@ -1249,6 +1332,7 @@ def test_bench_script_emits_parity_block_and_exit_code(dev):
     assert d2["batches_in_flight"] == 2 and d2["single_stream"]["value"] > 0 and d2["parity"]["mismatched_frames"] == 0
     assert "ONE HIP stream" in d2["roofline"]["measured_in"] and d2["roofline"]["in_timed_region"]["launches"] > 0
     out = subprocess.run(cmd + ["--batch", "5", "--height", "120", "--width", "160"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert out.returncode == 0 and "not a BASELINE config" in d["config"]["workload"]
     env["DCX_BENCH_CORRUPT_PARITY"] = "1"          # test hook: bench flips one result before the comparison

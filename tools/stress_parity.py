@@ -40,7 +40,7 @@ PLAN = {(64, 96): (0.40, 256), (120, 160): (0.30, 128), (240, 320): (0.25, 48), 
 def oracle_chunk(spec):
     """Worker: render the chunk's frames, run the oracle, write everything the GPU side needs to one .npz in shared memory."""
     import torch
-    cid, h, w, n, wseed, threads = spec
+    cid, h, w, n, wseed, threads, do_f64, do_bs1 = spec
     torch.set_num_threads(threads)
     from deepcharuco_amd import weights as W
     from oracle import deepcharuco_oracle as O
@@ -100,15 +100,21 @@ def oracle_chunk(spec):
         return cat(out, np.int64)
 
     # ---- the reference against ITSELF (1): one frame per call, same thread count (inference.py:32-70 is per frame) -- every 4th frame
-    loc_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[0] for b in sub])
-    ids_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[1] for b in sub])
+    if do_bs1:
+        loc_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[0] for b in sub])
+        ids_b1 = torch.cat([O.detector_forward(t_dc, x[b:b + 1])[1] for b in sub])
+    else:
+        loc_b1 = ids_b1 = torch.zeros(0)
     # ---- exact arithmetic: the same graph in float64 on the same float32 inputs and weights ("truth" for BOTH fp32 evaluations)
     # (in slices of <= 1.3 M pixels: float64 activations of a whole chunk would be 2x the fp32 pass's memory in every worker)
-    t64 = {k_: v.double() for k_, v in t_dc.items()}
-    step = max(1, (1 << 20) * 5 // 4 // (h * w))
-    parts = [O.detector_forward(t64, x[i:i + step].double()) for i in range(0, n, step)]
-    loc64, ids64 = torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
-    del parts, t64
+    if do_f64:
+        t64 = {k_: v.double() for k_, v in t_dc.items()}
+        step = max(1, (1 << 20) * 5 // 4 // (h * w))
+        parts = [O.detector_forward(t64, x[i:i + step].double()) for i in range(0, n, step)]
+        loc64, ids64 = torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
+        del parts, t64
+    else:
+        loc64 = ids64 = torch.zeros(0)
     # ---- the reference against ITSELF (2): the same tensors, one thread
     torch.set_num_threads(1)
     loc_1t, ids_1t = O.detector_forward(t_dc, x)
@@ -125,15 +131,16 @@ def oracle_chunk(spec):
     return path
 
 
-def main():
+def run(total=20000, workers=14, threads=16, do_f64=True, do_bs1=True, do_direct=True, plan=None, verbose=True,
+        summary_name="stress_parity_summary.json"):
+    """The whole comparison; returns the summary dict (also written to gpurun_out/<summary_name>).  tests/test_gpu_parity.py runs a
+    bounded slice of it (no float64 / one-frame-per-call / direct-family columns) with hard gates; `main` the full table."""
     import torch
-    total = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-    workers = int(sys.argv[2]) if len(sys.argv) > 2 else 14
-    threads = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    plan = PLAN if plan is None else plan
     specs, cid = [], 0
-    for (h, w), (share, per) in PLAN.items():
+    for (h, w), (share, per) in plan.items():
         for _ in range(int(np.ceil(total * share / per))):
-            specs.append((cid, h, w, per, 5000 + 7 * (cid % 61), threads))        # 61 different weight sets
+            specs.append((cid, h, w, per, 5000 + 7 * (cid % 61), threads, do_f64, do_bs1))        # 61 different weight sets
             cid += 1
     specs.sort(key=lambda s: -s[1] * s[2] * s[3])                                   # biggest chunks first
     from deepcharuco_amd import weights as W
@@ -217,7 +224,7 @@ def main():
                               "with the dust-bin threshold within +-2e-4 of a cell's own margin (fire/no-fire sampled where it is close)",
                "buckets": label, "results": res}
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "stress_parity_summary.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", summary_name), "w") as f:
             json.dump(out, f, indent=1)
         return out
 
@@ -242,12 +249,14 @@ def main():
                 xs = torch.stack([torch.from_numpy(pre_bgr_image(frames[b])) for b in sub]).to(dev)       # (S,1,h,w)
                 pos = {int(b): i for i, b in enumerate(sub)}
                 patches = torch.cat([extract_patches(xs[pos[int(b)]], torch.from_numpy(kp[kf == b]).to(dev)) for b in np.unique(kf)])
-            t_loc, t_ids = torch.from_numpy(z["loc64"]).to(dev), torch.from_numpy(z["ids64"]).to(dev)
-            compare_logits("oracle_f32_vs_f64", o_loc, o_ids, t_loc, t_ids)
-            for c, direct in (("hip_default", False), ("hip_direct", True)):
+            if do_f64:
+                t_loc, t_ids = torch.from_numpy(z["loc64"]).to(dev), torch.from_numpy(z["ids64"]).to(dev)
+                compare_logits("oracle_f32_vs_f64", o_loc, o_ids, t_loc, t_ids)
+            for c, direct in ((("hip_default", False), ("hip_direct", True)) if do_direct else (("hip_default", False),)):
                 set_deterministic(direct)
                 got = det.forward_u8(d_frames)
-                compare_logits(c + "_vs_f64", got["loc"], got["ids"], t_loc, t_ids)
+                if do_f64:
+                    compare_logits(c + "_vs_f64", got["loc"], got["ids"], t_loc, t_ids)
                 fire_o, o_ia = compare_logits(c, got["loc"], got["ids"], o_loc, o_ids)
                 if c == "hip_default":
                     ids_hist += torch.bincount(o_ia[fire_o], minlength=N_IDS + 1)[:N_IDS].cpu().numpy()
@@ -255,26 +264,49 @@ def main():
                     _, cor = ref.infer_patches(patches, torch.from_numpy(kp).to(dev))
                     compare_heat(c, (cor[:, 1] * 64 + cor[:, 0]).cpu().numpy(), z)
                 compare_e2e(c, infer_batch(frames[sub], N_IDS, lModel(det), lRefineNet(ref), kmax=128), z["finals"])     # end to end (every 4th frame)
-            set_deterministic(False)
+            if do_direct:
+                set_deterministic(False)
             # the reference against itself: one thread; one frame per call
             compare_logits("oracle_1thr", torch.from_numpy(z["loc_1t"]).to(dev), torch.from_numpy(z["ids_1t"]).to(dev), o_loc, o_ids)
             if kp.shape[0]:
                 compare_heat("oracle_1thr", z["heat_idx_1t"], z)
             compare_e2e("oracle_1thr", z["finals_1t"], z["finals"])
-            si = torch.from_numpy(np.asarray(sub)).to(dev)
-            compare_logits("oracle_bs1", torch.from_numpy(z["loc_b1"]).to(dev), torch.from_numpy(z["ids_b1"]).to(dev), o_loc[si], o_ids[si])
+            if do_bs1:
+                si = torch.from_numpy(np.asarray(sub)).to(dev)
+                compare_logits("oracle_bs1", torch.from_numpy(z["loc_b1"]).to(dev), torch.from_numpy(z["ids_b1"]).to(dev), o_loc[si], o_ids[si])
             frames_done += n
-            print(f"[{time.time() - t0:6.0f}s] {frames_done:6d} frames  ({w}x{h} x{n})  arg-max disagreements (loc+ids / heat / e2e frames):  " +
+            if verbose:
+                print(f"[{time.time() - t0:6.0f}s] {frames_done:6d} frames  ({w}x{h} x{n})  arg-max disagreements (loc+ids / heat / e2e frames):  " +
                   "  ".join(f"{c} {int(col[c]['stats']['loc']['disagree'].sum() + col[c]['stats']['ids']['disagree'].sum())}/"
                             f"{int(col[c]['stats']['heat']['disagree'].sum())}/{col[c]['e2e_bad']}" for c in COLS), flush=True)
             del det, ref
             chunks_done += 1
             if chunks_done % 25 == 0:
                 summarize()
-    out = summarize()
+    return summarize()
+
+
+def main():
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    total = int(argv[0]) if len(argv) > 0 else 20000
+    workers = int(argv[1]) if len(argv) > 1 else 14
+    threads = int(argv[2]) if len(argv) > 2 else 16
+    if "--slice" in sys.argv:
+        # the bounded slice tests/test_gpu_parity.py::test_stress_parity_slice gates on: product path + the oracle's own 1-thread
+        # noise floor against the N-thread reference pass; no float64 / one-frame-per-call / direct-family columns
+        out = run(total, workers, threads, do_f64=False, do_bs1=False, do_direct=False, verbose=False, summary_name="stress_parity_slice.json")
+        r = out["results"]
+        print(json.dumps({c: {"frames": r[c]["frames"], "max_abs_logit_diff": r[c]["max_abs_logit_diff"],
+                              "cells_decided_differently": r[c]["cells_decided_differently"], "end_to_end": r[c]["end_to_end"]}
+                          for c in ("hip_default", "oracle_1thr")}))
+        return
+    out = run(total, workers, threads)
+    COLS = ("hip_default", "hip_direct", "oracle_1thr", "oracle_bs1")
+    COLS64 = ("oracle_f32_vs_f64", "hip_default_vs_f64", "hip_direct_vs_f64")
+    label, nb, frames_done = out["buckets"], len(out["buckets"]), out["frames"]
     col = out["results"]
     print(f"\n{frames_done} frames; reference pass = oracle batched at {threads} threads; every column is compared with IT")
-    print("firing cells per id:", ids_hist.tolist())
+    print("firing cells per id:", out["firing_cells_per_id"])
     print(f"{'':24s}" + "".join(f"{c:>16s}" for c in COLS))
     print(f"{'max |logit diff|':24s}" + "".join(f"{col[c]['max_abs_logit_diff']:16.3e}" for c in COLS))
     print(f"{'mean |logit diff|':24s}" + "".join(f"{col[c]['mean_abs_logit_diff']:16.3e}" for c in COLS))
