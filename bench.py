@@ -54,6 +54,7 @@ DET_GFLOP_240x320 = 12.879052800  # 2 * 6,439,526,400 MAC   
 REF_GFLOP_PER_PATCH = 0.871072256  # 2 * 435,536,128 MAC
 REFERENCE_README_FPS = 200.0      # "> 200 fps" GTX1080Ti, bs=1 (README.md:42-44)
 FRAME_SEED = 1000
+SETTLE_S = 0.15                   # untimed settle phase ahead of the warm-up steps (GPU power state, RCCL lazy init): see run_config
 
 
 def pmc_traffic(kernel_name):
@@ -212,7 +213,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     pool = B * kmax
     n_i32 = packed_len(B, pool)
     dist_on = world > 1 or cx.force_dist      # --force-dist: the N>1 code path (process group, side-stream gather, barrier) with ONE rank
-    og = OverlappedGather(n_i32, dev, backend=cx.backend) if dist_on else None
+    og = OverlappedGather(n_i32, dev, backend=cx.backend, timing=True) if dist_on else None
     if og is not None:
         og.warm_up()      # RCCL's lazy initialisation (tens of ms over its first dozens of calls) is not steady-state throughput
     # Batches in flight: consecutive steps run on alternating HIP streams (the product's pipelined callers: stream.ResidentStream
@@ -260,19 +261,27 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- settle phase (set-up, not one of the W warm-up steps): untimed steps for SETTLE_S seconds before anything is counted.
+    # Two things need it.  (1) The GPU's power management: after the idle stretch in which the host renders the frames the GPU sits
+    # in a low power state; under load it raises the shader clock in steps, and ~30 ms into a run one transition stalls the stream for
+    # ~0.9 ms (per-batch GPU times of a cold 20-step run: 3.33, 3.24, 3.24, 4.08, 3.20 ... 3.12 ms; with the settle phase: 3.16, 3.13,
+    # 3.11 ... -- profiles/experiments/r06_power_state_ramp.txt).  W = 5 warm-up steps are 16 ms: a 20-step timed region would
+    # measure the ramp, not the path (that was the driver-run 9,617 fps of round 5 against the builder's 50-step 10,253).
+    # (2) N > 1: RCCL / c10d keep initialising lazily while the first collectives overlap real work (~50 ms of host-side stalls
+    # during the first ~35 steps, none afterwards -- tools/gather_overlap_probe.py).  The timed region is still EXACTLY K steps and
+    # every one of them is listed in step_breakdown.gpu_ms_per_batch.
+    settle_steps = 0
+    if SETTLE_S > 0:
+        t_s = time.perf_counter()
+        # N > 1: a FIXED count (every step is a collective: all ranks must run the same number); N = 1: by the clock
+        while (settle_steps < 48) if dist_on else (settle_steps < 4 or (time.perf_counter() - t_s < SETTLE_S and settle_steps < 400)):
+            step()
+            settle_steps += 1
+        fence()
+    state["settle_steps"] = settle_steps
     if profile:
         L.dcx_profile_filter(-1)
-        L.dcx_profile_enable(1)
-    if og is not None:
-        # RCCL / c10d keep initialising lazily while the first collectives overlap real work (measured: ~50 ms of host-side
-        # stalls during the first ~35 steps, none afterwards -- tools/gather_overlap_probe.py); these extra untimed steps take them
-        for _ in range(40):
-            step()
-        fence()
-        if profile:
-            L.dcx_profile_enable(1)      # restart the record list: the dominant-kernel choice uses the W warm-up steps only
-    for _ in range(int(getattr(cx, "preroll", 0))):      # experiment knob (--preroll): untimed steps ahead of the W warm-up steps
-        step()
+        L.dcx_profile_enable(1)          # the dominant-kernel choice uses the W warm-up steps
     for _ in range(max(0, S - warmup)):      # set-up, not warm-up: every stream's scratch buffers exist before anything is timed
         step()
     for _ in range(warmup):
@@ -303,6 +312,7 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         state["host_step_s"] = time.perf_counter() - t0          # host time until the last step is enqueued (before the drain)
         fence()
         el = time.perf_counter() - t0
+        state["el_local"] = el
         if dist_on:
             t = torch.tensor([el], dtype=torch.float64, device=dev if cx.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -310,6 +320,17 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
         return el
 
     elapsed = timed_pass(steps)              # THE timed region: `value`
+    per_rank_info = None
+    if dist_on:
+        # every rank's own clock and its exchange step, so that a multi-GPU line is diagnosable in one shot: ms_per_step of the
+        # rank (before the MAX over ranks), duration of the side-stream exchange (event pair around all_gather_into_tensor + the
+        # D2H of the gathered lists), and whether it stayed under a step's convolutions
+        gm = np.asarray(og.gather_ms[-steps:] if og.gather_ms else [], dtype=np.float64)
+        mine = {"rank": rank, "device": int(dev.index), "ms_per_step": round(1e3 * state["el_local"] / steps, 4),
+                "gather_ms": ({"median": round(float(np.median(gm)), 4), "max": round(float(gm.max()), 4), "n": int(gm.size)} if gm.size else None)}
+        mine["gather_overlapped"] = bool(og.overlapped and (gm.size == 0 or float(np.median(gm)) < mine["ms_per_step"]))
+        per_rank_info = [None] * world
+        dist.all_gather_object(per_rank_info, mine)
     # host / per-batch GPU timers of the timed region (N = 1: stream.ResidentStream keeps them)
     rs_stats = None
     if og is None:
@@ -491,6 +512,9 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
     out = {
         "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / steps, 4), "steps": steps,
         "warmup": warmup,
+        "settle": {"steps": state["settle_steps"], "seconds": SETTLE_S,
+                   "why": "untimed set-up ahead of the W warm-up steps: GPU power state (clock ramp + one ~0.9 ms stall ~30 ms into a run)"
+                          + (" and RCCL / c10d lazy initialisation" if dist_on else "")},
         "batches_in_flight": S,
         "config": {"workload": WL.workload_label(B, H, Wd, world, fixed_k), "preset": name,
                    "batch_per_gpu": B, "global_batch": B * world, "height": H, "width": Wd,
@@ -514,7 +538,8 @@ def run_config(cx, name, batch, height, width, kmax, frames_kind, fixed_k, steps
                                 "ms_per_step": round(1e3 * elapsed_1s / steps, 4), "steps": steps,
                                 "note": "the same steps on ONE HIP stream (one batch in flight): the pass the roofline block is measured in"}
     if dist_on:
-        out["gather_overlapped"] = bool(og.overlapped)
+        out["gather_overlapped"] = bool(og.overlapped) and all(p["gather_overlapped"] for p in per_rank_info)
+        out["per_rank"] = per_rank_info
     if roofline is not None:
         out["roofline"] = roofline
         out["step_breakdown"] = state.get("breakdown")
@@ -671,7 +696,9 @@ def main():
                          "Default 1: with EQUAL work in every batch a second stream gains nothing (-1 ... -4 %, "
                          "profiles/experiments/r05_batches_in_flight_equal_work.txt); > 1 adds a single-stream pass for the roofline block")
     ap.add_argument("--parity-frames", type=int, default=8)
-    ap.add_argument("--preroll", type=int, default=0, help="experiment: extra untimed steps ahead of the warm-up steps")
+    ap.add_argument("--settle", type=float, default=None,
+                    help=f"seconds of untimed steps ahead of the warm-up steps (default {SETTLE_S}; 0 = none: the cold A/B that shows the "
+                         "GPU's clock ramp inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs (the other BASELINE configs, bs=1 protocol)")
@@ -702,7 +729,9 @@ def main():
     cx.dist = None
     cx.force_dist = bool(args.force_dist)
     cx.streams = args.streams
-    cx.preroll = args.preroll
+    if args.settle is not None:
+        global SETTLE_S
+        SETTLE_S = max(0.0, float(args.settle))
     dist_on = world > 1 or cx.force_dist
     if dist_on:
         import torch.distributed as dist
@@ -772,7 +801,7 @@ def main():
     }
     if dist_on:
         line["ranks"] = cx.ranks_seen
-    for k_ in ("batches_in_flight", "single_stream", "gather_overlapped", "step_breakdown", "roofline", "cpu_baseline"):
+    for k_ in ("settle", "batches_in_flight", "single_stream", "gather_overlapped", "per_rank", "step_breakdown", "roofline", "cpu_baseline"):
         if k_ in main_res:
             line[k_] = main_res[k_]
     if others:

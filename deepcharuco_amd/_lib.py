@@ -78,6 +78,8 @@ SIGNATURES = {
     "dcx_conv_pick_name_ups": (C.c_char_p, [_i] * 9),
     "dcx_set_deterministic": (_i, [_i]),
     "dcx_get_deterministic": (_i, []),
+    "dcx_set_tail_fence": (_i, [_i]),
+    "dcx_get_tail_fence": (_i, []),
     "dcx_profile_enable": (_i, [_i]),
     "dcx_profile_count": (_i, []),
     "dcx_profile_filter": (_i, [_i]),

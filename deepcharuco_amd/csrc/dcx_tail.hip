@@ -28,6 +28,7 @@
 // logits while they are in the accumulators), delivered per corner -- the "confidences" model_utils.py:81-84 mentions.
 #include "dcx_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 typedef float dcx_t_f32x16 __attribute__((ext_vector_type(16)));
@@ -125,7 +126,10 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
                                                         const float4* __restrict__ w_ids, const float* __restrict__ b_ids,
                                                         int ids_cout_pad, int n_ids1, int tiles_per_frame, int dust_bin,
                                                         int32_t* codes, int32_t* __restrict__ loc_argmax,
-                                                        int32_t* __restrict__ ids_argmax, DcxPoolOut po) {
+                                                        int32_t* __restrict__ ids_argmax, DcxPoolOut po, int fence) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "dcx_tail_kernel's fence-free hand-off counts on gfx942 / gfx950 behaviour (stores are tracked by vmcnt; sc1 stores / loads are write-through / L2-bypassing at agent scope): build with DCX_TAIL_FENCE semantics reviewed for any other ISA"
+#endif
     constexpr int NPIX = 32 * NT;
     __shared__ float red_v[4 + 1][NPIX];     // [job: loc tile 0..2, ids tile 0..1][pixel]
     __shared__ int red_i[4 + 1][NPIX];
@@ -272,15 +276,31 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
     //      wave drains its stores, then ONE lane draws the frame's ticket (relaxed agent-scope atomic); the workgroup that draws the
     //      last one reads the frame's codes with agent-scope (sc1) loads, which bypass its L1.  (Round 5's first version had every
     //      thread of every work item run __threadfence() on both sides: 30 -> 136 us at bs=32.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    //      INVARIANT the fast path rests on: `codes` and `po.conf_cells` are ONLY ever written with agent-scope atomic stores and read
+    //      with agent-scope atomic loads (dcx_ld_agent) -- a plain store / load added to either side would go through a non-coherent
+    //      L2 / L1 and break the hand-off silently.  `fence` != 0 (DCX_TAIL_FENCE=1 / dcx_set_tail_fence) selects the textbook
+    //      release / acquire pair the HIP memory model defines instead: the A/B for new ROCm drops and other ISAs (~4x slower).
+    if (fence) __threadfence();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(&po.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles_per_frame - 1;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&po.tickets[b], 1, fence ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles_per_frame - 1;
     __syncthreads();
     if (!s_last) return;
+    if (fence) __threadfence();
     dcx_tail_compact_frame<CONF>(codes, cells, dust_bin, b, po, s_cnt, &s_bcast);
 }
 
 }  // namespace
+
+// Hand-off mode of the fused compaction: 0 (default) = fence-free (write-through stores + one relaxed ticket + agent-scope loads),
+// 1 = __threadfence() on both sides (release / acquire as the HIP memory model defines it).  DCX_TAIL_FENCE=1 or dcx_set_tail_fence.
+static int g_tail_fence = -1;
+static int dcx_tail_fence_mode() {
+    if (g_tail_fence < 0) { const char* e = getenv("DCX_TAIL_FENCE"); g_tail_fence = (e && atoi(e)) ? 1 : 0; }
+    return g_tail_fence;
+}
+extern "C" int dcx_set_tail_fence(int enabled) { g_tail_fence = enabled ? 1 : 0; return 0; }
+extern "C" int dcx_get_tail_fence(void) { return dcx_tail_fence_mode(); }
 
 // act: C4 [B][act_cq_total = 128][cells][4] (convPa|convDa output); w_*: packed [cin/4 = 64][cout_pad][4]; codes [B][cells].
 // po (nullable): fused ordered compaction into the batch's corner pool; po->tickets[0..batch) and *po->cursor must be 0 at entry.
@@ -311,7 +331,7 @@ int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, 
     const float4* wi = reinterpret_cast<const float4*>(w_ids);
 #define DCX_TAIL_LAUNCH(NT, IT, CF)                                                                                      \
     hipLaunchKernelGGL((dcx_tail_kernel<NT, IT, CF>), dim3((unsigned)items), dim3(256), 0, s, a4, 128, cells, wl, b_loc, wi, b_ids, \
-                       ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax, po)
+                       ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax, po, dcx_tail_fence_mode())
     if (two) { if (conf) DCX_TAIL_LAUNCH(1, 2, true); else DCX_TAIL_LAUNCH(1, 2, false); }
     else     { if (conf) DCX_TAIL_LAUNCH(1, 1, true); else DCX_TAIL_LAUNCH(1, 1, false); }
 #undef DCX_TAIL_LAUNCH

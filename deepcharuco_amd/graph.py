@@ -83,6 +83,28 @@ class _DeviceLocks:
     def all(self):
         return _DeviceLocks._All(self)
 
+    def try_all(self) -> Optional[list]:
+        """Non-blocking attempt at every device's lock -> the held locks (release with ``release_all``) or None.  For callers that
+        must never wait (model destructors, which may run from the garbage collector inside any critical section)."""
+        if not self._all.acquire(blocking=False):
+            return None
+        held = []
+        n = max(torch.cuda.device_count() if torch.cuda.is_available() else 0, 1)
+        for i in range(n):
+            lk = self.device(i)
+            if not lk.acquire(blocking=False):
+                for h in reversed(held):
+                    h.release()
+                self._all.release()
+                return None
+            held.append(lk)
+        return held
+
+    def release_all(self, held: list) -> None:
+        for lk in reversed(held):
+            lk.release()
+        self._all.release()
+
 
 _locks = _DeviceLocks()
 
@@ -98,6 +120,10 @@ class GraphedPipeline:
         # cycle that only the cyclic GC frees (~25 MB of workspace + pinned buffers per shape); with weak ones the graphs die with
         # the model by reference count
         self._det, self._ref = weakref.ref(det), (None if ref is None else weakref.ref(ref))
+        # the C handles the graph's kernel arguments point into: a replay first checks that the models still own exactly these
+        # (a reload / .to() / destruction frees the weights the captured launches read)
+        self._det_handle = det.handle.value
+        self._ref_handle = None if ref is None else ref.handle.value
         self.batch, self.h, self.w, self.kmax, self.bgr = batch, height, width, kmax, bgr
         self.pool = batch * kmax
         self.zero_copy = int(os.environ.get("DCX_GRAPH_ZEROCOPY", "2")) if zero_copy is None else int(zero_copy)
@@ -127,6 +153,18 @@ class GraphedPipeline:
                 self._enqueue()
         self._in_np = self.pin_in.numpy()
         self._out_np = self.pin_out.numpy()
+        with _cache_lock:
+            _live.add(self)           # every pipeline that exists, cached or evicted-but-still-held (drop_graphs_of_* close them all)
+
+    def _models_unchanged(self) -> bool:
+        det = self._det()
+        if det is None or det._handle is None or det._handle.value != self._det_handle:
+            return False
+        if self._ref is not None:
+            ref = self._ref()
+            if ref is None or ref._handle is None or ref._handle.value != self._ref_handle:
+                return False
+        return True
 
     @property
     def deepc(self):
@@ -166,6 +204,9 @@ class GraphedPipeline:
             graph, in_np, out_np = self.graph, self._in_np, self._out_np
             if graph is None:
                 raise ReferenceError("this GraphedPipeline has been closed (its models were released)")
+            if not self._models_unchanged():      # reloaded / moved / destroyed since the capture: the graph points at freed weights
+                self.close()
+                raise ReferenceError("the models this graph was captured with have been released or reloaded")
             if frames.shape != in_np.shape or frames.dtype != np.uint8:
                 raise ValueError(f"expected uint8 frames of shape {in_np.shape}, got {frames.dtype} {frames.shape}")
             np.copyto(in_np, frames)
@@ -203,6 +244,7 @@ _cache_lock = threading.RLock()         # re-entrant: dropping a pipeline may ru
 _graph_lock = _locks.all                # `with _graph_lock():` = every device's lock (capture, destruction, cache surgery)
 _graveyard: list = []                   # hipGraphs / buffers of closed pipelines; list.append / pop are atomic
 _caches: "weakref.WeakSet" = weakref.WeakSet()     # the per-detector caches that exist (for clear_graph_cache())
+_live: "weakref.WeakSet" = weakref.WeakSet()       # every GraphedPipeline that exists (cached, or evicted but still held by a thread)
 
 
 def _drain() -> None:
@@ -247,37 +289,44 @@ def clear_graph_cache(deepc=None) -> None:
         _drain()
 
 
+def _try_drain() -> None:
+    """Empty the graveyard if nobody is replaying or capturing right now; never waits (see ``drop_graphs_of_detector``)."""
+    if not _graveyard:
+        return
+    held = _locks.try_all()
+    if held is not None:
+        try:
+            _drain()
+        finally:
+            _locks.release_all(held)
+
+
+def _close_pipelines_of(match) -> None:
+    """Retire every pipeline -- cached or evicted-but-still-held -- for which ``match(pipeline)`` holds.  Takes ONLY the cache lock
+    (re-entrant) and never waits for a device lock: this runs from model destructors, i.e. possibly from the garbage collector in
+    the middle of any critical section of this module (a destructor that took the device locks while its thread already held the
+    cache lock deadlocked against a capturing thread: ADVICE r5).  ``close`` itself is lock-free; what it leaves behind is destroyed
+    by the next holder of all device locks (a capture, ``clear_graph_cache``) or right here if nobody is replaying.  A thread that
+    is about to replay a retired pipeline is stopped by ``run``'s own check of the models' C handles."""
+    with _cache_lock:
+        victims = [p for p in list(_live) if match(p)]
+        for c in list(_caches):
+            for k in [k for k, p in c.items() if p in victims]:
+                c.pop(k, None)
+    _retire(victims)
+    del victims
+    _try_drain()
+
+
 def drop_graphs_of_detector(det) -> None:
     """Called when a detector releases its C handle: its graphs hold pointers into the freed weights."""
-    if not getattr(det, "_graph_cache", None):      # nothing captured with it (checked unlocked: the caller owns the detector)
-        return
-    with _graph_lock():
-        victims = []
-        with _cache_lock:
-            cache = getattr(det, "_graph_cache", None)
-            if cache:
-                victims = list(cache.values())
-                cache.clear()
-        _retire(victims)
-        del victims
-        _drain()
+    _close_pipelines_of(lambda p: p._det() is det or p._det() is None)
 
 
 def drop_graphs_of_refiner(ref) -> None:
     """Called when a RefineNet releases its C handle (reload / ``to(device)`` / destruction): graphs captured with it hold
     pointers into the freed weights."""
-    with _cache_lock:
-        if not any(k[0] is not None and k[0][0] == id(ref) for c in list(_caches) for k in c):
-            return
-    with _graph_lock():
-        victims = []
-        with _cache_lock:
-            for c in list(_caches):
-                for k in [k for k in c if k[0] is not None and k[0][0] == id(ref)]:
-                    victims.append(c.pop(k, None))
-        _retire(victims)
-        del victims
-        _drain()
+    _close_pipelines_of(lambda p: p._ref is not None and (p._ref() is ref or p._ref() is None))
 
 
 def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int, bgr: bool,
@@ -298,6 +347,8 @@ def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int
             cache = det._graph_cache = _Cache()
             _caches.add(cache)
         p = cache.pop(key, None)
+        if p is not None and p.graph is None:                 # retired (a model was released / reloaded): a miss, capture again
+            p = None
         if p is not None:
             cache[key] = p                                    # most recently used last
         return cache, p
@@ -317,6 +368,7 @@ def cached_pipeline(dust_bin_ids: int, deepc, refinenet, height: int, width: int
                 while len(cache) >= _CACHE_MAX:
                     evicted.append(cache.pop(next(iter(cache))))
                 cache[key] = p
-            del evicted           # not closed: a thread that still holds one finishes its call; __del__ retires it afterwards
+            del evicted           # not closed: a thread that still holds one finishes its call (it stays in _live, so a model
+                                  # release still retires it); __del__ retires it afterwards
             _drain()
     return p

@@ -320,9 +320,16 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
     if _graphs_enabled() and graphs_usable():
         try:
             from .graph import cached_pipeline
-            pipe = cached_pipeline(dust_bin_ids, deepc, refinenet, img.shape[0], img.shape[1], bgr=frame.ndim == 4)
-            keypoints = pipe.run(frame)[0]
-        except (_lib.DcxError, ValueError, ReferenceError):
+            for attempt in (0, 1):
+                pipe = cached_pipeline(dust_bin_ids, deepc, refinenet, img.shape[0], img.shape[1], bgr=frame.ndim == 4)
+                try:
+                    keypoints = pipe.run(frame)[0]
+                    break
+                except ReferenceError:
+                    # another thread retired this pipeline between the lookup and the replay (a model of the pair was reloaded or
+                    # the cache was cleared): look it up / capture it once more, then fall through to the eager launches
+                    continue
+        except (_lib.DcxError, ValueError):
             raise
         except RuntimeError as e:      # graph capture unavailable: same kernels, launched eagerly
             if not _graph_state["warned"]:

@@ -221,6 +221,15 @@ const char* dcx_conv_pick_name_ups(int n, int cin, int ho, int wo, int cout, int
 int dcx_set_deterministic(int enabled);
 int dcx_get_deterministic(void);
 
+/* ---- hand-off mode of the detector tail's fused compaction (csrc/dcx_tail.hip) --------------
+ * 0 (default): the frame's last work item learns about the other work items' codes without fences -- write-through (sc1) stores
+ * drained by s_waitcnt vmcnt(0), one relaxed agent-scope ticket, agent-scope (sc1) loads: gfx942 / gfx950 behaviour, soaked by
+ * tests/test_gpu_parity.py::test_tail_handoff_is_never_stale.  1 (or DCX_TAIL_FENCE=1 in the environment): the release / acquire
+ * pair the HIP memory model defines (__threadfence() on both sides, ~4x the kernel's time): the A/B for new ROCm drops.
+ * Same results either way.  Process-global; captured hipGraphs keep the mode they were captured with.                  */
+int dcx_set_tail_fence(int enabled);
+int dcx_get_tail_fence(void);
+
 /* ---- instrumentation: per-launch profile of the MFMA convolution kernel (roofline) ---------
  * While enabled, every launch of the convolution kernel is bracketed by two hipEvents on its
  * stream and recorded.  dcx_profile_enable(1) clears the record list.  After the caller has
@@ -238,6 +247,8 @@ int dcx_profile_sample(int every);   /* bracket only every `every`-th matching l
                                         every launch */
 int dcx_profile_fetch(int* kernel_ids, int* n_images, int* limited, double* flops_per_image, float* ms,
                       int max_records);
+/* kernel_id < 100: the convolution instantiation table; 100..103: the pipeline's other launches (detector conv1a, RefineNet
+ * conv1a + patch gather, detector tail, refine finalize), recorded with flops_per_image = 0 while no filter is set */
 const char* dcx_profile_kernel_name(int kernel_id);
 /* effective shader clock (GHz) seen by workgroup 0 of each recorded launch: s_memtime ticks per
  * s_memrealtime (100 MHz) tick between its first and last instruction.  Same order as _fetch. */

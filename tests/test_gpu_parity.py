@@ -699,7 +699,7 @@ def test_config5_resolution_1280x960(dev):
     from deepcharuco_amd.models.net import dcModel, lModel
     from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
     frames = W.synthetic_frames("board", 900, 2, 960, 1280)
-    sd_dc = _calibrated(91, frames[:1], target_per_frame=16)
+    sd_dc = _calibrated(91, frames, target_per_frame=16)      # on BOTH frames: 32 corners in the batch, well inside its 128-slot pool
     sd_rn = W.synthetic_state_dict("refinenet", 92)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(sd_rn, dev))
     res = infer_batch(frames, 16, dc, rn, kmax=64)
@@ -989,6 +989,32 @@ ref = weakref.ref(dc2.model)
 del dc2, rn2
 gc.collect()
 assert ref() is None
+print("STEP lifetime", flush=True)
+# (5) a pipeline a thread still HOLDS (here: evicted from the cache by hand) must not replay after a model of the pair was
+#     reloaded -- its launches point at freed weights (ADVICE r5): run() checks the C handles, infer_image recovers by re-capturing
+kp, _ = I.infer_image(imgs[3], 16, dc, rn, device="cuda")
+held = next(iter(dc.model._graph_cache.values()))
+dc.model._graph_cache.clear()                           # "evicted": only `held` and the module's live set know it now
+assert np.array_equal(held.run(imgs[3][None])[0], exp[3])
+old_handle = rn.model.handle.value
+rn.to(dev)                                              # reload: frees the old handle's weights, drops every pipeline captured with it
+assert held.graph is None                               # retired although it was in no cache
+try:
+    held.run(imgs[3][None])
+    raise SystemExit("a retired pipeline replayed")
+except ReferenceError:
+    pass
+kp, _ = I.infer_image(imgs[3], 16, dc, rn, device="cuda")
+assert np.array_equal(kp, exp[3]) and len(dc.model._graph_cache) == 1
+held2 = next(iter(dc.model._graph_cache.values()))
+held2._ref_handle = 12345                               # a stale handle value (as if the drop had been missed): the replay refuses
+try:
+    held2.run(imgs[3][None])
+    raise SystemExit("a pipeline with a stale handle replayed")
+except ReferenceError:
+    pass
+kp, _ = I.infer_image(imgs[3], 16, dc, rn, device="cuda")     # infer_image: ReferenceError -> looks the pipeline up again -> re-captures
+assert np.array_equal(kp, exp[3])
 print("RESULT ok", flush=True)
 """
 
@@ -1649,8 +1675,11 @@ def test_inference_model_wrapper(dev, golden_tiny, tmp_path):
     assert m2.refinenet is None and kp2.dtype == np.int64 and np.array_equal(kp2, golden_tiny.fx["final_norn"])
 
 
-def test_tail_handoff_is_never_stale(dev):
-    """The detector tail hands its per-cell codes to the frame's last work item without fences (write-through stores, one ticket,
+@pytest.mark.parametrize("fence", [0, 1])
+def test_tail_handoff_is_never_stale(dev, fence):
+    """(fence = 1: the same soak with the __threadfence() release / acquire hand-off, dcx_set_tail_fence -- the A/B kept compilable
+    for new ROCm drops; both modes must give the same bits.)
+    The detector tail hands its per-cell codes to the frame's last work item without fences (write-through stores, one ticket,
     agent-scope loads; csrc/dcx_tail.hip) and the code buffer is reused by every call.  A stale read would return the PREVIOUS
     call's code for a cell, which repeated runs on the same frames can never show -- so: three different batches (different
     content in every frame slot, different corner counts) alternate through ONE workspace, 150 calls at bs=32 and 150 at bs=1,
@@ -1664,15 +1693,20 @@ def test_tail_handoff_is_never_stale(dev):
     sd_dc = _calibrated(5101, np.concatenate([b[:3] for b in batches]), target_per_frame=16)
     dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 5102), dev))
     d = [torch.from_numpy(b).to(dev) for b in batches]
+    from deepcharuco_amd import _lib
+    L = _lib.lib()
 
     def canon(packed, b):
         res, counts = unpack_results(packed.cpu().numpy(), b, b * 64, True)
         return counts.tobytes() + b"".join(np.ascontiguousarray(r).tobytes() for r in res)
     for bs in (32, 1):
+        L.dcx_set_tail_fence(0)
         want = []
         for x in d:          # reference results: each batch in a fresh workspace
             want.append(canon(infer_batch_device(x[:bs], 16, lModel(dcModel(16, sd_dc, dev)), rn, 64), bs))
         assert len(set(want)) == 3                           # the batches really differ
+        L.dcx_set_tail_fence(fence)
+        assert L.dcx_get_tail_fence() == fence
         side = torch.cuda.Stream()
         noise = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
         bad = 0
@@ -1684,7 +1718,8 @@ def test_tail_handoff_is_never_stale(dev):
             got = canon(infer_batch_device(d[k][:bs], 16, dc, rn, 64), bs)
             bad += got != want[k]
         torch.cuda.synchronize()
-        assert bad == 0, f"bs={bs}: {bad} of 150 calls differ from the fresh-workspace result"
+        L.dcx_set_tail_fence(0)
+        assert bad == 0, f"bs={bs}, fence={fence}: {bad} of 150 calls differ from the fresh-workspace result"
 
 
 @pytest.mark.gpu
