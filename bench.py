@@ -730,8 +730,7 @@ def main():
     cx.force_dist = bool(args.force_dist)
     cx.streams = args.streams
     if args.settle is not None:
-        global SETTLE_S
-        SETTLE_S = max(0.0, float(args.settle))
+        globals()["SETTLE_S"] = max(0.0, float(args.settle))
     dist_on = world > 1 or cx.force_dist
     if dist_on:
         import torch.distributed as dist
