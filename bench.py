@@ -628,33 +628,6 @@ def bs1_reference_protocol(cx, n_iter=500):
             "vs_reference_readme_200fps": round(n_iter / el / REFERENCE_README_FPS, 2)}
 
 
-def exploratory_bf16x3():
-    """EXPLORATORY, never the headline: conv1b (64 -> 64, 3x3, 240x320) on the BF16 matrix pipe with every fp32 operand split into
-    three bf16 terms (six cross products, fp32 accumulate) -- tools/ubench/bf16x3_conv.hip, a stand-alone prototype that is not
-    part of the library.  Reports its error against fp64 next to the fp32 fmaf chain's on the same outputs, and its rate."""
-    import re
-    import subprocess
-    exe = os.path.join(REPO, "tools", "ubench", "bf16x3_conv")
-    if not os.path.exists(exe):
-        return None
-    try:
-        out = subprocess.run([exe, "32"], capture_output=True, text=True, timeout=120).stdout
-    except Exception as e:      # noqa
-        return {"error": repr(e)}
-    res = {"dtype": "bf16x3: fp32 operands split into three bf16 terms, six bf16 MFMA cross products, fp32 accumulation",
-           "layer": "detector conv1b (64->64, 3x3, pad 1) on 32 frames of 320x240, raw accumulators",
-           "note": "stand-alone prototype kernels (tools/ubench/bf16x3_conv.hip), NOT on the product path and not in `value`; "
-                   "the product runs this layer on the fp32 pipe (Winograd, ~265 TFLOP/s algorithmic)"}
-    for line in out.splitlines():
-        m = re.match(r"bf16x3 (\d) terms( \(LDS-staged\))?:\s+([\d.]+) ms .*?([\d.]+) TFLOP/s .*bf16x3 max ([\d.e+-]+) mean ([\d.e+-]+)\s+fp32 fmaf chain .* max ([\d.e+-]+) mean ([\d.e+-]+)", line)
-        if m:
-            key = f"{m.group(1)}_terms" + ("_lds_staged" if m.group(2) else "")
-            res[key] = {"ms": float(m.group(3)), "tflops_fp32_equivalent": float(m.group(4)),
-                        "max_abs_err_vs_fp64": float(m.group(5)), "mean_abs_err_vs_fp64": float(m.group(6)),
-                        "fp32_fmaf_chain_max_abs_err_vs_fp64": float(m.group(7)), "fp32_fmaf_chain_mean_abs_err_vs_fp64": float(m.group(8))}
-    return res
-
-
 def self_launch(n, backend, argv):
     """`python bench.py --gpus N` from a bare shell (no RANK/WORLD_SIZE in the environment) for N > 1: start the N ranks
     ourselves under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port), forward every flag,
@@ -775,10 +748,6 @@ def main():
         if world == 1:
             others["cfg2_two_batches_in_flight"] = two_stream_pipelined(cx)
             others["bs1_reference_protocol"] = bs1_reference_protocol(cx)
-            if rank == 0:
-                ex = exploratory_bf16x3()
-                if ex is not None:
-                    others["exploratory_bf16x3_conv1b"] = ex
 
     if rank != 0:
         if dist_on:

@@ -881,7 +881,32 @@ def test_bgr2gray_device_kernel_equals_the_fixed_point_formula(dev):
     for v in ("opencv4", "legacy14"):
         assert np.array_equal(bgr2gray_device(d_cube, v).cpu().numpy(), O.bgr2gray(cube, v)), v
     n_dif = int((O.bgr2gray(cube, "opencv4") != O.bgr2gray(cube, "legacy14")).sum())
-    _report("bgr2gray", dict(cube_triples=int(cube.shape[0] * cube.shape[1]), variants_differ_on=n_dif, random_triples_differ=differ))
+    # a1 pin (inference.py:40): where OpenCV exists on the box, the device kernel of the variant the installed cv2 computes -- and the
+    # pipeline's DCX_PIX_BGR8 entry -- are compared with cv2.cvtColor ITSELF on the whole colour cube; where it does not, the report
+    # says so (the formula is then all there is: OpenCV 4.x color.hpp constants, parity unpinned for this one step)
+    from deepcharuco_amd import imgproc
+    cv2 = imgproc._opencv()
+    if cv2:
+        variant = imgproc.bgr2gray_variant_of_module(cv2)
+        ref_gray = cv2.cvtColor(cube, cv2.COLOR_BGR2GRAY)
+        got = bgr2gray_device(d_cube, variant).cpu().numpy()
+        cv2_pin = dict(cv2=cv2.__version__, variant=variant, cube_mismatches_device_kernel=int((got != ref_gray).sum()),
+                       default_variant_matches=bool(variant == imgproc.DEFAULT_BGR2GRAY))
+        assert cv2_pin["cube_mismatches_device_kernel"] == 0, cv2_pin
+        # the pipeline's own BGR load (conv1a + RefineNet's patch gather) against the gray frame cv2 produced, end to end
+        from deepcharuco_amd.inference import infer_batch
+        case = __import__("conftest").GoldenCase("img7412_240x320")
+        dc_, rn_ = _models(case, dev)
+        g_cv = cv2.cvtColor(case.bgr, cv2.COLOR_BGR2GRAY)
+        a = infer_batch(case.bgr[None], 16, dc_, rn_, bgr_variant=variant)[0]
+        b = infer_batch(g_cv[None], 16, dc_, rn_)[0]
+        cv2_pin["pipeline_bgr_entry_equals_cv2_gray_entry"] = bool(a.shape == b.shape and np.array_equal(a, b))
+        assert cv2_pin["pipeline_bgr_entry_equals_cv2_gray_entry"]
+    else:
+        cv2_pin = dict(cv2="absent", note="device kernels == the OpenCV 4.x fixed-point formula on the whole cube; cv2.cvtColor itself not run")
+    print("a1 pin:", cv2_pin)
+    _report("bgr2gray", dict(cube_triples=int(cube.shape[0] * cube.shape[1]), variants_differ_on=n_dif, random_triples_differ=differ,
+                             opencv=cv2_pin))
     edge = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
     assert bgr2gray_device(torch.from_numpy(edge).to(dev)).cpu().numpy().tolist() == [[255, 0, 29, 150, 76]]
     with pytest.raises(ValueError):
