@@ -78,6 +78,9 @@ SIGNATURES = {
     "dcx_conv_pick_name_ups": (C.c_char_p, [_i] * 9),
     "dcx_set_deterministic": (_i, [_i]),
     "dcx_get_deterministic": (_i, []),
+    "dcx_calibrate_xcd": (_i, [_i, C.POINTER(C.c_float), _vp]),
+    "dcx_set_xcd_weights": (_i, [C.POINTER(C.c_float)]),
+    "dcx_get_xcd_weights": (_i, [C.POINTER(C.c_float)]),
     "dcx_set_tail_fence": (_i, [_i]),
     "dcx_get_tail_fence": (_i, []),
     "dcx_profile_enable": (_i, [_i]),

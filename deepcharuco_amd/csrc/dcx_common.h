@@ -56,6 +56,14 @@ struct DcxConvArgs {
     int cout_real;         // un-padded output channels (profiling only)
     int tiles_x, tiles_y;
     int xcd_walk;          // set by the launcher: XCD-aware item walk
+    const int* xcd_cum;    // set by the launcher: device table [9]; XCD x walks items [total * cum[x] >> 16, total * cum[x + 1] >> 16),
+                           // cum[0] = 0, cum[8] = 65536.  Equal eighths by default; dcx_calibrate_xcd / dcx_set_xcd_weights re-weight the
+                           // ranges by measured per-XCD speed (the XCDs of one chip differ by 3-6 % under this load).  Same items, same
+                           // bits.  A table is immutable once a launch may read it (a new weight set gets a new table), so all
+                           // workgroups of a launch -- and every replay of a captured graph -- see ONE partition.  (Through a pointer
+                           // rather than nine kernel arguments: the unpooled kernels sit at the SGPR limit.)
+    unsigned long long* xcd_stat;   // nullable [17]: calibration launches only -- [x] += s_memrealtime at the exit of every workgroup
+                                    // of XCD x, [8] = start time of workgroup 0, [9 + x] += 1
     int ct_outer;          // set by the launcher (2-D Winograd kernels): work items ordered cout tile OUTERMOST (image inside), so that
                            // with the XCD-aware walk an XCD works on one or two cout tiles at a time -- for layers whose transformed
                            // weights (16 x cin x cout x 4 B: 4.2 MB for the fused 512-cout heads) do not fit an XCD's 4 MB L2 next to

@@ -133,6 +133,17 @@ struct DcxItem {   // one work item = (image, cout tile, [phase,] spatial tile);
 //   (u+1)&1 one step later, so global-memory latency and the staging index math hide behind
 //   16 MFMAs (1024 cycles) per step.  Only the first unit of a workgroup is staged synchronously.
 //   One barrier per unit.  Weights (A) and LDS reads (B) are fetched one k-step ahead.
+// First work item of XCD x's share: the equal eighth, moved by the weighted deviation in WHOLE CU-ROUNDS (32 items = one item for each
+// of an XCD's 32 CUs), rounded to the nearest.  A launch lasts as long as its busiest CU, so a share that is not a multiple of 32 only
+// adds a round to a few CUs: with near-equal weights or few items per XCD the deviation rounds to 0 and the split is exactly the equal
+// one (a launch of 5 items per workgroup must not become one of 6 for three workgroups: measured -5.5 % on the whole step with
+// unquantised shares); a 1.25 % weight moves a boundary of conv1b (2,400 items per XCD) by one round.
+__device__ __forceinline__ int dcx_xcd_bound(int total, int x, int cum) {
+    const int eq = (int)(((long)total * x) >> 3);
+    const int dev = (int)(((long)total * (cum - (x << 13))) >> 16);
+    return eq + ((dev + (dev >= 0 ? 16 : -16)) / 32) * 32;
+}
+
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(const DcxConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sB[];
@@ -158,8 +169,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_mfma_kernel(cons
     int w = blockIdx.x, w_end = total, gstride = gridDim.x;
     if (a.xcd_walk && (gridDim.x & 7) == 0) {
         const int x = blockIdx.x & 7;
-        const int lo = (int)(((long)total * x) >> 3);
-        w_end = (int)(((long)total * (x + 1)) >> 3);
+        const int lo = dcx_xcd_bound(total, x, a.xcd_cum[x]);           // equal eighths unless the launcher re-weighted the XCDs
+        w_end = dcx_xcd_bound(total, x + 1, a.xcd_cum[x + 1]);
         gstride = gridDim.x >> 3;
         w = lo + (blockIdx.x >> 3);
     }
@@ -582,6 +593,7 @@ constexpr int DCX_MAX_DEVICES = 64;
 int dcx_current_device();    // hipGetDevice() clamped to [0, DCX_MAX_DEVICES)
 int dcx_occupancy_override();
 int dcx_xcd_walk_enabled();   // DCX_XCD_WALK=0 keeps the flat item walk (A/B runs)
+void dcx_fill_xcd_cum(DcxConvArgs& a);   // the current device's cumulative XCD weights (dcx_conv_mfma.hip)
 
 template <class C>
 static int dcx_conv_launch_cfg(DcxConvArgs a, hipStream_t stream) {
@@ -594,6 +606,7 @@ static int dcx_conv_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const long resident = (long)dcx_device_cu_count() * (occ_env > 0 && occ_env < C::OCC ? occ_env : C::OCC);   // persistent workgroups
     const long blocks = items < resident ? items : resident;
     a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
+    dcx_fill_xcd_cum(a);
     static bool attr_set[DCX_MAX_DEVICES] = {};      // the attribute is per device (multi-GPU processes)
     const int dev_i = dcx_current_device();
     if (!attr_set[dev_i]) {

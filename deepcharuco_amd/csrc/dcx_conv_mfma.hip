@@ -298,6 +298,140 @@ int dcx_xcd_walk_enabled() {
     return v;
 }
 
+// ---- per-XCD item-range weights -------------------------------------------------------------------------------------------------
+// The eight XCDs of one MI355X do not run this load at the same speed (3-6 % between the fastest and the slowest, a property of the
+// chip: profiles/experiments/r06_xcd_weights.txt), and a launch ends with its slowest XCD.  The XCD-aware walk therefore gives XCD x
+// the items [total * cum[x], total * cum[x + 1]) with cum from these weights (equal until dcx_calibrate_xcd / dcx_set_xcd_weights).
+namespace {
+// Device tables of cumulative shares, [kXcdTables][16] ints per device, used round robin: a table is written ONCE (before any launch
+// can read it) and never modified afterwards, so every workgroup of a launch -- and every replay of a hipGraph captured with it -- sees
+// one partition even while the host installs new weights; a slot is only reused after kXcdTables further weight changes.
+constexpr int kXcdTables = 256;
+int* g_xcd_tab[DCX_MAX_DEVICES] = {};
+int g_xcd_next[DCX_MAX_DEVICES] = {};
+const int* g_xcd_cur[DCX_MAX_DEVICES] = {};
+float g_xcd_w[DCX_MAX_DEVICES][8];
+int xcd_set(int dev, const float* w8) {
+    if (g_xcd_tab[dev] == nullptr)
+        DCX_CHECK_HIP(hipMalloc((void**)&g_xcd_tab[dev], sizeof(int) * 16 * kXcdTables));
+    double sum = 0.0;
+    for (int x = 0; x < 8; ++x) { g_xcd_w[dev][x] = w8 ? w8[x] : 1.0f; sum += g_xcd_w[dev][x]; }
+    double acc = 0.0;
+    int cum[16] = {};
+    for (int x = 0; x < 8; ++x) {
+        g_xcd_w[dev][x] = (float)(g_xcd_w[dev][x] / sum);
+        acc += g_xcd_w[dev][x];
+        cum[x + 1] = x == 7 ? 65536 : (int)(acc * 65536.0 + 0.5);
+    }
+    int* slot = g_xcd_tab[dev] + 16 * (g_xcd_next[dev]++ % kXcdTables);
+    DCX_CHECK_HIP(hipMemcpy(slot, cum, sizeof(cum), hipMemcpyHostToDevice));      // synchronous: complete before any launch that uses it
+    g_xcd_cur[dev] = slot;
+    return 0;
+}
+}  // namespace
+
+void dcx_fill_xcd_cum(DcxConvArgs& a) {
+    const int dev = dcx_current_device();
+    if (g_xcd_cur[dev] == nullptr) (void)xcd_set(dev, nullptr);      // first launch on this device (never under graph capture: the
+                                                                      // callers warm up eagerly first)
+    a.xcd_cum = g_xcd_cur[dev];
+}
+
+// w8: relative speeds of XCD 0..7 of the CURRENT device (any positive scale; NULL = equal).  Weights further than 25 % from equal
+// are refused (a measurement gone wrong must not starve an XCD).  Speed only: the set of work items and their bits do not change.
+extern "C" int dcx_set_xcd_weights(const float* w8) {
+    if (w8 != nullptr) {
+        double sum = 0.0;
+        for (int x = 0; x < 8; ++x) { if (!(w8[x] > 0.f)) return DCX_E_ARG; sum += w8[x]; }
+        for (int x = 0; x < 8; ++x) { const double r = 8.0 * w8[x] / sum; if (r < 0.75 || r > 1.25) return DCX_E_ARG; }
+    }
+    return xcd_set(dcx_current_device(), w8);
+}
+extern "C" int dcx_get_xcd_weights(float* w8) {
+    if (!w8) return DCX_E_ARG;
+    const int dev = dcx_current_device();
+    if (g_xcd_cur[dev] == nullptr) { const int rc = xcd_set(dev, nullptr); if (rc) return rc; }
+    for (int x = 0; x < 8; ++x) w8[x] = 8.0f * g_xcd_w[dev][x];      // 1.0 = an equal share
+    return 0;
+}
+
+namespace {
+// pseudo-random operand values for the calibration launches: the matrix pipe's power draw -- and with it the per-XCD clock behaviour
+// under test -- depends on the operands (constant operands showed a quarter of the spread random ones do)
+__global__ void dcx_fill_hash_kernel(float* __restrict__ p, size_t n, float lo, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = lo + scale * (float)(h >> 8) * (1.0f / 16777216.0f);
+    }
+}
+}  // namespace
+
+// Measures the XCDs of the current device and sets their weights: `rounds` launches of the dominant kernel's own instantiation on a
+// synthetic conv1b-sized layer (64 -> 64, 3x3, pooled, 32 frames of 320x240: 19,200 work items, 37.5 per workgroup, ~0.8 ms each),
+// every workgroup adding its end time to its XCD's sum; speed of XCD x = its item share / its mean workgroup duration, averaged
+// over the rounds after two warm-up launches.  Synchronous (set-up code: call it once the GPU is warm, outside any timed region and
+// outside hipGraph capture); ~0.8 GB of scratch is allocated and freed.  w8_out (nullable): the weights set (1.0 = equal share).
+extern "C" int dcx_calibrate_xcd(int rounds, float* w8_out, void* stream) {
+    if (rounds < 1 || rounds > 64) return DCX_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = 32, c = 64, h = 240, w = 320;
+    const size_t in_elems = (size_t)n * c * h * w, out_elems = in_elems / 4, w_elems = (size_t)16 * c * c;
+    float *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_ab = nullptr;
+    unsigned long long* d_stat = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_w); (void)hipFree(d_ab); (void)hipFree(d_stat); };
+    hipError_t e = hipMalloc((void**)&d_in, in_elems * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_elems * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_w, w_elems * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ab, 3 * c * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_stat, 17 * 8);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)d_ab, 0x3f800000, 3 * c, s);         // alpha = beta = bias = 1
+    if (e != hipSuccess) { cleanup(); return (int)e; }
+    hipLaunchKernelGGL(dcx_fill_hash_kernel, dim3(4096), dim3(256), 0, s, d_in, in_elems, -1.0f, 2.0f);
+    hipLaunchKernelGGL(dcx_fill_hash_kernel, dim3(64), dim3(256), 0, s, d_w, w_elems, -0.05f, 0.1f);
+    if ((e = hipGetLastError()) != hipSuccess) { cleanup(); return (int)e; }
+    DcxConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_in; a.w = d_w; a.w_wino2 = d_w; a.bias = d_ab; a.alpha = d_ab + c; a.beta = d_ab + 2 * c; a.out = d_out;
+    a.n = n; a.in_cq_total = c / 4; a.cin = c; a.hin = h; a.win = w; a.pad = 1; a.ho = h; a.wo = w;
+    a.out_cq_total = c / 4; a.cout_pad = c; a.cout_quads = c / 4; a.cout_real = c;
+    const int dev = dcx_current_device();
+    float keep[8];
+    for (int x = 0; x < 8; ++x) keep[x] = g_xcd_cur[dev] != nullptr ? g_xcd_w[dev][x] : 0.125f;
+    (void)xcd_set(dev, nullptr);                             // measure with equal shares
+    double speed[8] = {};
+    int rc = 0, used = 0;
+    for (int r = 0; r < rounds + 2 && rc == 0; ++r) {
+        if ((e = hipMemsetAsync(d_stat, 0, 17 * 8, s)) != hipSuccess) { rc = (int)e; break; }
+        a.xcd_stat = r >= 2 ? d_stat : nullptr;
+        rc = dcx_launch_conv_mfma(a, 3, 1, DCX_EPI_BNRELU, s);
+        if (rc != 0 || r < 2) continue;
+        unsigned long long hst[17];
+        if ((e = hipMemcpyAsync(hst, d_stat, sizeof(hst), hipMemcpyDeviceToHost, s)) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) { rc = (int)e; break; }
+        bool ok = hst[8] != 0;
+        double dur[8];
+        for (int x = 0; x < 8 && ok; ++x) {
+            ok = hst[9 + x] > 0;
+            if (ok) { dur[x] = (double)hst[x] / (double)hst[9 + x] - (double)hst[8]; ok = dur[x] > 0.0; }
+        }
+        if (!ok) continue;                                   // e.g. the flat walk (DCX_XCD_WALK=0): nothing to weight
+        for (int x = 0; x < 8; ++x) speed[x] += 1.0 / dur[x];
+        ++used;
+    }
+    (void)hipStreamSynchronize(s);
+    cleanup();
+    if (rc == 0 && used > 0) {
+        float w8[8];
+        for (int x = 0; x < 8; ++x) w8[x] = (float)(speed[x] / used);
+        rc = dcx_set_xcd_weights(w8);
+    } else if (rc == 0) {
+        rc = DCX_E_SHAPE;
+    }
+    if (rc != 0) (void)xcd_set(dev, keep);
+    if (rc == 0 && w8_out != nullptr) (void)dcx_get_xcd_weights(w8_out);
+    return rc;
+}
+
 int dcx_occupancy_override() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("DCX_OCC"); v = e ? atoi(e) : 0; }

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
     int w = blockIdx.x, w_end = total, gstride = gridDim.x;
     if (a.xcd_walk && (gridDim.x & 7) == 0) {
         const int x = blockIdx.x & 7;
-        const int lo = (int)(((long)total * x) >> 3);
-        w_end = (int)(((long)total * (x + 1)) >> 3);
+        const int lo = dcx_xcd_bound(total, x, a.xcd_cum[x]);           // equal eighths unless the launcher re-weighted the XCDs
+        w_end = dcx_xcd_bound(total, x + 1, a.xcd_cum[x + 1]);
         gstride = gridDim.x >> 3;
         w = lo + (blockIdx.x >> 3);
     }
@@ -173,6 +173,10 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         a.clk_probe[0] = __builtin_amdgcn_s_memtime();
         a.clk_probe[1] = __builtin_amdgcn_s_memrealtime();
     }
+    // calibration launches (dcx_calibrate_xcd) run the dominant kernel's instantiation only: the other instantiations carry no
+    // code for it (the unpooled ones sit at the SGPR limit: one more live pointer spilled a VGPR)
+    constexpr bool XSTAT = C::POOL && C::TW == 16 && C::TB == 2 && C::G == 1;
+    if (XSTAT && a.xcd_stat != nullptr && blockIdx.x == 0 && tid == 0) a.xcd_stat[8] = __builtin_amdgcn_s_memrealtime();
 #ifdef DCX_W2H_BLOCKTIMES      // tuning aid (tools/block_times.py): every workgroup's start / end time; overruns the launch's own probe slot
     if (a.clk_probe != nullptr && tid == 0) a.clk_probe[64 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -578,6 +582,10 @@ __global__ __launch_bounds__(256, 2) void dcx_conv_wino2h_kernel(const DcxConvAr
         }
 
         if (!has_next) {
+            if (XSTAT && a.xcd_stat != nullptr && tid == 0) {       // calibration launches (dcx_calibrate_xcd): per-XCD sum of the workgroups' end times
+                atomicAdd(&a.xcd_stat[blockIdx.x & 7], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+                atomicAdd(&a.xcd_stat[9 + (blockIdx.x & 7)], 1ull);
+            }
 #ifdef DCX_W2H_BLOCKTIMES
             if (a.clk_probe != nullptr && tid == 0) a.clk_probe[65 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -615,6 +623,7 @@ static int dcx_conv_wino2h_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const long resident = (occ_env == 1 ? 1L : 2L) * dcx_device_cu_count();
     const long blocks = items < resident ? items : resident;
     a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
+    dcx_fill_xcd_cum(a);
     {   // cout tile outermost where the layer's transformed weights would otherwise thrash the XCDs' L2 (DCX_CT_OUTER=0/1 forces it)
         static int force = -2;
         if (force == -2) { const char* e = getenv("DCX_CT_OUTER"); force = e ? atoi(e) : -1; }

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256, DCX_W2P_OCC) DCX_W2P_ATTR void dcx_conv_wino2p
     int w = blockIdx.x, w_end = total, gstride = gridDim.x;
     if (a.xcd_walk && (gridDim.x & 7) == 0) {
         const int x = blockIdx.x & 7;
-        const int lo = (int)(((long)total * x) >> 3);
-        w_end = (int)(((long)total * (x + 1)) >> 3);
+        const int lo = dcx_xcd_bound(total, x, a.xcd_cum[x]);           // equal eighths unless the launcher re-weighted the XCDs
+        w_end = dcx_xcd_bound(total, x + 1, a.xcd_cum[x + 1]);
         gstride = gridDim.x >> 3;
         w = lo + (blockIdx.x >> 3);
     }
@@ -544,6 +544,7 @@ static int dcx_conv_wino2p_launch_cfg(DcxConvArgs a, hipStream_t stream) {
     const long resident = (long)(occ_env >= 1 && occ_env < DCX_W2P_OCC ? occ_env : DCX_W2P_OCC) * dcx_device_cu_count();
     const long blocks = items < resident ? items : resident;
     a.xcd_walk = dcx_xcd_walk_enabled() && blocks == resident && (resident & 7) == 0 ? 1 : 0;
+    dcx_fill_xcd_cum(a);
     static bool attr_set[DCX_MAX_DEVICES] = {};
     const int dev_i = dcx_current_device();
     if (!attr_set[dev_i]) {

@@ -8,6 +8,7 @@ and exists so every mirrored function is exercised end to end; both return ident
 """
 from __future__ import annotations
 
+import ctypes as _ctypes
 import warnings
 from typing import List, Optional
 
@@ -22,7 +23,8 @@ from .models.net import dcModel, lModel
 from .models.refinenet import RefineNet, lRefineNet
 
 __all__ = ["load_models", "infer_image", "infer_image_staged", "infer_batch", "infer_batch_device", "unpack_results", "packed_len",
-           "solve_pnp", "solve_pnp_batch", "solve_pnp_submit", "set_deterministic", "InferenceModel"]
+           "solve_pnp", "solve_pnp_batch", "solve_pnp_submit", "set_deterministic", "InferenceModel", "calibrate_xcd",
+           "set_xcd_weights", "get_xcd_weights"]
 
 DEFAULT_KMAX = 64
 
@@ -116,6 +118,41 @@ def set_deterministic(enabled: bool = True) -> None:
     _lib.check(_lib.lib().dcx_set_deterministic(1 if enabled else 0), "dcx_set_deterministic")
     from .graph import clear_graph_cache
     clear_graph_cache()          # captured graphs froze the kernels chosen under the previous mode
+
+
+def calibrate_xcd(device="cuda", rounds: int = 8) -> List[float]:
+    """Measure the eight XCDs of ``device`` and re-weight the convolution kernels' per-XCD item shares (``dcx_calibrate_xcd``).
+
+    The XCDs of one MI355X run this load 3-6 % apart and a launch ends with its slowest XCD; with shares proportional to the
+    measured speeds they finish together.  Speed only -- work items and bits are unchanged.  Set-up code: synchronous (~10 ms,
+    0.8 GB of scratch allocated and freed), call it once the GPU is warm (after a few batches), never inside a timed region.
+    Graphs captured before keep their old shares, so the graph cache is cleared.  Returns the weights (1.0 = an equal share)."""
+    dev = require_cuda(device)
+    w = (_ctypes.c_float * 8)()
+    with torch.cuda.device(dev):
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().dcx_calibrate_xcd(int(rounds), w, _lib.current_stream()), "dcx_calibrate_xcd")
+    from .graph import clear_graph_cache
+    clear_graph_cache()
+    return [float(v) for v in w]
+
+
+def set_xcd_weights(weights=None, device="cuda") -> None:
+    """Per-XCD item shares by hand: 8 relative speeds, ``None`` = equal (``dcx_set_xcd_weights``)."""
+    dev = require_cuda(device)
+    arr = None if weights is None else (_ctypes.c_float * 8)(*[float(v) for v in weights])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().dcx_set_xcd_weights(arr), "dcx_set_xcd_weights")
+    from .graph import clear_graph_cache
+    clear_graph_cache()
+
+
+def get_xcd_weights(device="cuda") -> List[float]:
+    dev = require_cuda(device)
+    w = (_ctypes.c_float * 8)()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().dcx_get_xcd_weights(w), "dcx_get_xcd_weights")
+    return [float(v) for v in w]
 
 
 def _unwrap(deepc, refinenet):

@@ -230,6 +230,17 @@ int dcx_get_deterministic(void);
 int dcx_set_tail_fence(int enabled);
 int dcx_get_tail_fence(void);
 
+/* ---- per-XCD item shares (speed only; the work items and their bits do not change) ---------
+ * The convolution kernels are persistent grids whose workgroups walk one contiguous share of the item list per XCD (8 XCDs, each
+ * with its own L2).  The XCDs of one chip do not run this load equally fast (3-6 % apart), and a launch ends with its slowest XCD:
+ * dcx_calibrate_xcd measures them (`rounds` ~0.8 ms launches of the dominant kernel on a synthetic conv1b-sized layer; synchronous,
+ * set-up code: GPU warm, outside timed regions and hipGraph capture) and sets the shares accordingly; dcx_set_xcd_weights sets
+ * them by hand (8 relative speeds, NULL = equal; more than 25 % from equal is refused with DCX_E_ARG); dcx_get_xcd_weights returns
+ * them (1.0 = an equal share).  Per device (the current one), process-global; hipGraphs keep the shares they were captured with. */
+int dcx_calibrate_xcd(int rounds, float* w8_out, void* stream);
+int dcx_set_xcd_weights(const float* w8);
+int dcx_get_xcd_weights(float* w8);
+
 /* ---- instrumentation: per-launch profile of the MFMA convolution kernel (roofline) ---------
  * While enabled, every launch of the convolution kernel is bracketed by two hipEvents on its
  * stream and recorded.  dcx_profile_enable(1) clears the record list.  After the caller has

@@ -412,6 +412,47 @@ def test_infer_image_vs_golden(dev, golden):
         assert kp2.dtype == np.int64 and np.array_equal(kp2, fx["final_norn"])
 
 
+def test_xcd_weights_change_the_speed_not_the_bits(dev):
+    """dcx_set_xcd_weights / dcx_calibrate_xcd move the boundaries between the eight XCDs' shares of a launch's item list (whole
+    CU-rounds of 32 items): every work item must still be done exactly once -- same packed result, bit for bit, for skewed shares,
+    for calibrated ones and for equal ones, at bs=32 (big launches: boundaries move) and bs=3 (small launches: they must not);
+    out-of-range weights are refused."""
+    from deepcharuco_amd import _lib
+    from deepcharuco_amd.inference import calibrate_xcd, get_xcd_weights, infer_batch_device, set_xcd_weights
+    from deepcharuco_amd.models.net import dcModel, lModel
+    from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
+    frames = W.synthetic_frames("board", 6100, 32, 240, 320)
+    sd_dc = _calibrated(6101, frames[:4], target_per_frame=16)
+    dc, rn = lModel(dcModel(16, sd_dc, dev)), lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 6102), dev))
+    d = torch.from_numpy(frames).to(dev)
+
+    from deepcharuco_amd.inference import unpack_results
+
+    def canon(n):
+        p = infer_batch_device(d[:n], 16, dc, rn, 64).cpu().numpy()
+        res, counts = unpack_results(p, n, n * 64, True)
+        return counts.tobytes() + b"".join(np.ascontiguousarray(r).tobytes() for r in res)
+    try:
+        set_xcd_weights(None, dev)
+        assert get_xcd_weights(dev) == [1.0] * 8
+        want32, want3 = canon(32), canon(3)
+        for w in ([1.2, 0.8, 1.1, 0.9, 1.0, 1.05, 0.95, 1.0], [0.8, 1.2, 0.85, 1.15, 1.0, 1.0, 1.1, 0.9], [1.0125, 0.9875] * 4):
+            set_xcd_weights(w, dev)
+            got = get_xcd_weights(dev)
+            assert abs(sum(got) - 8.0) < 1e-4 and all(abs(a / sum(w) * 8 - b) < 1e-4 for a, b in zip(w, got))
+            assert canon(32) == want32 and canon(3) == want3, w
+        cal = calibrate_xcd(dev, 4)
+        assert len(cal) == 8 and abs(sum(cal) - 8.0) < 1e-3 and all(0.75 <= v <= 1.25 for v in cal)
+        assert canon(32) == want32 and canon(3) == want3
+        _report("xcd_weights", dict(calibrated=cal))
+        import ctypes
+        bad = (ctypes.c_float * 8)(*([2.0] + [1.0] * 7))
+        assert _lib.lib().dcx_set_xcd_weights(bad) == -1                 # DCX_E_ARG: more than 25 % from an equal share
+        assert _lib.lib().dcx_calibrate_xcd(0, None, None) == -1
+    finally:
+        set_xcd_weights(None, dev)
+
+
 def test_stress_parity_slice(dev):
     """A bounded slice of tools/stress_parity.py IN the driver-run suite: ~1,750 seeded frames at the four
     resolutions 96x64 ... 640x480, ~22 weight sets, a third of the chunks with all 16 ids firing, every second chunk with the

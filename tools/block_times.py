@@ -17,6 +17,10 @@ x = torch.randn(n, cin, h, w, generator=g).to(dev)
 wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
 b = torch.randn(cout, generator=g) * 0.1
 bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+if os.environ.get("BT_WEIGHTS"):      # per-XCD item shares (dcx_set_xcd_weights): e.g. BT_WEIGHTS=1.0125,0.9875,1.0125,0.9875,1.0125,0.9875,1.0125,0.9875
+    from deepcharuco_amd.inference import set_xcd_weights, get_xcd_weights
+    set_xcd_weights([float(v) for v in os.environ["BT_WEIGHTS"].split(",")], dev)
+    print("XCD weights:", " ".join(f"{v:.4f}" for v in get_xcd_weights(dev)))
 for _ in range(2):
     T._conv_layer(x, wt, b, bn, 1, 0, bool(pool), 3)
 L.dcx_profile_filter(-1); L.dcx_profile_enable(1)
