@@ -2,6 +2,7 @@
 // choice (cost model) per launch.
 #include "dcx_conv_mfma.h"
 #include "dcx_conv_wino2h.h"
+#include "dcx_conv_wino2hs.h"
 #include "dcx_conv_wino2p.h"
 
 #include <stdlib.h>
@@ -43,6 +44,13 @@ struct CfgEntry {
       &dcx_conv_wino2h_launch_cfg<DcxWino2hCfg<TH, TW, (POOL) != 0, 1, 1>>,                                \
       "dcx_conv_wino2h_kernel<DcxWino2hCfg<" #TH "," #TW "," #POOL ",1,1>>" }
 
+// the same family with an item's 16 positions split over the waves of the workgroup (dcx_conv_wino2hs.h): launches that cannot fill
+// the chip (one frame, ~16 patches); 16 CG couts x 16 tiles per item, acc_tiles = 1 marks them for the cost model
+#define DCX_W2HSCFG(POOL, CG)                                                                         \
+    { 16 * CG, 64, 8, 8, 3, POOL, DCX_EPI_BNRELU, 1, 0, 1, FAM_W2H,                                          \
+      &dcx_conv_wino2hs_launch_cfg<DcxWino2hsCfg<(POOL) != 0, CG>>,                                        \
+      "dcx_conv_wino2hs_kernel<DcxWino2hsCfg<" #POOL "," #CG ">>" }
+
 // x2 up-sampled input: 2-D Winograd F(2x2,2x2) per phase (dcx_conv_wino2p.h): th x tw is a LOW-RESOLUTION tile of one phase
 #define DCX_W2PCFG(TH, TW, EPI, G)                                                                    \
     { 64, 128, TH, TW, 3, 0, EPI, 5, 0, G, FAM_W2P,                                                          \
@@ -73,6 +81,8 @@ const CfgEntry kCfgs[] = {
     DCX_W2HCFG(8, 8, 0, 2),   // two whole 8x8 maps (RefineNet conv3a / conv3b) per work item
     DCX_W2HCFG_S(8, 8, 0),    // small launches (bs = 1: one frame, ~16 patches)
     DCX_W2HCFG_S(8, 8, 1),
+    DCX_W2HSCFG(0, 4), DCX_W2HSCFG(0, 2), DCX_W2HSCFG(0, 1),      // positions split over waves: single-round launches only
+    DCX_W2HSCFG(1, 4), DCX_W2HSCFG(1, 2), DCX_W2HSCFG(1, 1),
     // ---- phase x Winograd family: every 3x3 + BN + ReLU layer (cin >= 32) that reads a x2 up-sampled input
     DCX_W2PCFG(8, 16, DCX_EPI_BNRELU, 1),
     DCX_W2PCFG(8, 16, DCX_EPI_HEAT, 1),
@@ -135,6 +145,14 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
                                          // and where 32-tile items quantise badly (conv4a / conv4b at bs = 32: 768 items on 512 slots;
                                          // measured 60.0 vs 63.5 us), nowhere else (conv3a 121 vs 107 us, heads 229 vs 196: tools/layer_table.py)
                 item_cost = (double)units * (32 * 64.0 + 600.0) + 2000.0;
+            if (c.acc_tiles == 1) {      // dcx_conv_wino2hs.h: a wave's chain is 4 positions; the cout_tile / 16 waves of a SIMD interleave theirs.
+                                         // Only where every item gets a CU of its own (a launch = one item's chain): the smallest cout tile
+                                         // that still fits wins.  DCX_W2HS=<mask> restricts the choice (0: none; A/B runs)
+                static int w2hs = -1;     // bit mask of the cout-group counts in the choice (1 | 2 | 4)
+                if (w2hs < 0) { const char* e = getenv("DCX_W2HS"); w2hs = e ? atoi(e) : 7; }
+                if (!(w2hs & (c.cout_tile / 16)) || items > n_cu) continue;
+                item_cost = (double)units * (8 * 64.0 * (c.cout_tile / 16) + 400.0) + 1200.0;
+            }
             cost = (double)((items + n_cu - 1) / n_cu) * item_cost * (1.0 + 1e-6 * (double)items);   // ties: fewer work items
         } else if (c.fam == FAM_W2P) {   // 9 x 8 MFMAs of 32 cycles per unit; tiles are low-resolution, x4 phases
             const long wt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);

@@ -298,7 +298,8 @@ def test_kernel_family_depends_on_the_layer_only():
     launch size (all tiles of a family give identical bits: test_every_conv_instantiation_bit_exact)."""
     from deepcharuco_amd import _lib
     L = _lib.lib()
-    fam = lambda nm: nm[nm.index("dcx_conv_") + 9:nm.index("_kernel")]
+    # (dcx_conv_wino2hs.h is the wino2h FAMILY -- the same summation orders -- in the shape for launches that cannot fill the chip)
+    fam = lambda nm: nm[nm.index("dcx_conv_") + 9:nm.index("_kernel")].replace("wino2hs", "wino2h")
     det = [(64, 64, 1, 1), (64, 64, 2, 0), (64, 64, 2, 1), (64, 128, 4, 0), (128, 128, 4, 1), (128, 128, 8, 0), (128, 512, 8, 0)]
     ref = [(64, 64, 20, 0, 0, 0), (64, 128, 18, 0, 0, 0), (128, 128, 16, 1, 0, 0), (128, 128, 8, 0, 0, 0), (128, 128, 16, 0, 0, 1),
            (128, 128, 16, 0, 0, 0), (128, 64, 32, 0, 0, 1), (64, 64, 32, 0, 0, 0), (64, 64, 64, 0, 2, 1)]
@@ -328,8 +329,11 @@ def test_tile_cost_model_choices():
     assert "DcxWino2hCfg<6,20,0,1>" in name(512, 64, 18, 18, 128, 3, 0, 0)                 # RefineNet conv2a: 18x18 map in 3 tiles of 6x20
     assert "DcxWino2hCfg<6,20,0,1>" in name(32, 128, 30, 40, 512, 3, 0, 0)                 # fused heads' 3x3 (512 couts): 30x40 = 5 x 2 tiles
     assert "DcxWino2hCfg<8,8,0,2>" in name(512, 128, 8, 8, 128, 3, 0, 0)                   # RefineNet conv3a/3b: two maps per item
-    assert "DcxWino2hCfg<8,8,0,1,1>" in name(16, 128, 8, 8, 128, 3, 0, 0)                  # ... at bs=1 (16 patches): 16-tile items, half the serial chain (same bits)
-    assert "DcxWino2hCfg<8,8,0,1,1>" in name(1, 128, 30, 40, 128, 3, 0, 0)                 # conv4a for ONE frame: 40 short items instead of 24 long ones
+    assert "DcxWino2hsCfg<0,1>" in name(16, 128, 8, 8, 128, 3, 0, 0)                       # ... at bs=1 (16 patches): positions split over waves, 16 couts per workgroup: 128 short chains (same bits)
+    assert "DcxWino2hsCfg<0,1>" in name(1, 128, 30, 40, 128, 3, 0, 0)                      # conv4a for ONE frame: 160 quarter-length items instead of 40
+    assert "DcxWino2hsCfg<0,4>" in name(1, 128, 30, 40, 512, 3, 0, 0)                      # the fused heads of one frame: 160 items of 64 couts, four waves per SIMD
+    assert "DcxWino2hsCfg<1,2>" in name(16, 128, 16, 16, 128, 3, 1, 0)                     # RefineNet conv2b, 16 patches: 256 items of 32 couts
+    assert "DcxWino2hCfg<8,16,0,1>" in name(16, 64, 18, 18, 128, 3, 0, 0)                  # ... conv2a (288 items even at 64 couts): more than one round -> the bs=32 kernels
     assert "DcxWino2hCfg<8,8,0,1,1>" in name(32, 128, 30, 40, 128, 3, 0, 0)                # ... and where 32-tile items quantise badly (768 items on 512 slots: measured 60 vs 63.5 us)
     assert "DcxWino2hCfg<8,16,0,1>" in name(32, 64, 60, 80, 128, 3, 0, 0)                  # ... but not where the chip is well filled (conv3a: 107 vs 121 us)
     assert "DcxWino2hCfg<8,16,0,1>" in name(128, 128, 60, 80, 128, 3, 0, 0)                # (conv4a of cfg3)
