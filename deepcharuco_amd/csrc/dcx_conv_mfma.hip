@@ -4,6 +4,7 @@
 #include "dcx_conv_wino2h.h"
 #include "dcx_conv_wino2hs.h"
 #include "dcx_conv_wino2p.h"
+#include "dcx_conv_wino2ps.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -61,6 +62,12 @@ struct CfgEntry {
 // (Round 4 trimmed the direct family from 18 to 6 instantiations: on the default path it only runs the raw 1x1 heads; the 3x3
 //  tiles below are what deterministic mode -- the A/B reference of the Winograd families -- needs to run every layer shape, not a
 //  tuned set: the 12x20 / 6x40 / 16x16 / 10x20 / 6x18 / 8x16 / 4x1-wave variants were speed-ups of a mode no BASELINE config uses.)
+// ... and its small-launch shape (dcx_conv_wino2ps.h): 9 positions split over 3 CG waves, 16 CG couts x 16 low-resolution tiles per item
+#define DCX_W2PSCFG(CG)                                                                               \
+    { 16 * CG, 64, 8, 8, 3, 0, DCX_EPI_BNRELU, 1, 0, 1, FAM_W2P,                                             \
+      &dcx_conv_wino2ps_launch_cfg<DcxWino2psCfg<CG>>,                                                     \
+      "dcx_conv_wino2ps_kernel<DcxWino2psCfg<" #CG ">>" }
+
 const CfgEntry kCfgs[] = {
     // ---- direct family: the 1x1 heads, deterministic mode (every layer), cin < 32
     // 3x3 + BN + ReLU
@@ -87,6 +94,7 @@ const CfgEntry kCfgs[] = {
     DCX_W2PCFG(8, 16, DCX_EPI_BNRELU, 1),
     DCX_W2PCFG(8, 16, DCX_EPI_HEAT, 1),
     DCX_W2PCFG(8, 8, DCX_EPI_BNRELU, 2),   // two whole 8x8 low-resolution maps (RefineNet conv4a) per work item
+    DCX_W2PSCFG(4), DCX_W2PSCFG(2), DCX_W2PSCFG(1),      // positions split over waves: single-round launches only
 };
 
 // Deterministic mode (dcx_set_deterministic / DCX_DETERMINISTIC=1): every layer runs on the direct family -- each multiply-add
@@ -157,7 +165,14 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
         } else if (c.fam == FAM_W2P) {   // 9 x 8 MFMAs of 32 cycles per unit; tiles are low-resolution, x4 phases
             const long wt = (long)((ho / 2 + c.th - 1) / c.th) * ((wo / 2 + c.tw - 1) / c.tw);
             const long items = (long)((n + c.group - 1) / c.group) * (cout_pad / c.cout_tile) * wt * 4;
-            const double item_cost = (double)units * (72 * 32.0 + 500.0) + 2400.0;
+            double item_cost = (double)units * (72 * 32.0 + 500.0) + 2400.0;
+            if (c.acc_tiles == 1) {      // dcx_conv_wino2ps.h: a wave's chain is 3 positions; 3 cout_tile / 16 waves share four SIMDs.  As for
+                                         // dcx_conv_wino2hs.h: only where every item gets a CU of its own (DCX_W2PS=<mask of cout groups>, 0 = off)
+                static int w2ps = -1;
+                if (w2ps < 0) { const char* e = getenv("DCX_W2PS"); w2ps = e ? atoi(e) : 7; }
+                if (!(w2ps & (c.cout_tile / 16)) || items > n_cu) continue;
+                item_cost = (double)units * (12 * 32.0 * ((3 * (c.cout_tile / 16) + 3) / 4) + 400.0) + 1200.0;
+            }
             cost = (double)((items + n_cu - 1) / n_cu) * item_cost * (1.0 + 1e-6 * (double)items);
         } else {
             const long tiles = (long)((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);

@@ -54,6 +54,9 @@ struct DcxWino2hsCfg {
                                                             // workgroup is 512 matrix cycles: one unit of lead covered a third of the latency
     static_assert(CG == 1 || CG == 2 || CG == 4, "1, 2 or 4 cout groups");
     static_assert(U >= 2 && U <= 4, "ring depth");
+    // CG = 4 (1,024 threads: 128 registers per wave): ONE set of weight registers -- the next unit's weights of a position pair are
+    // requested into the pair's registers as soon as its MFMAs are issued (half a unit = 1,024 matrix cycles of lead)
+    static constexpr bool HALFROT = CG == 4;
     static_assert(OCC * LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -224,7 +227,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino2hs_kernel(c
 
     dcx_f32x4 acc[4];
     constexpr int U = C::U;                       // units in flight: raw tiles and weights are requested U - 1 units ahead of their use
-    float4 aq[U][4];                              // weights of unit c + i sit in aq[(c + i) % U]
+    constexpr int UW = C::HALFROT ? 1 : U;
+    float4 aq[UW][4];                             // weights of unit u sit in aq[u % UW]
     float4 rq[U][ITER_R];                         // raw float4 of unit u sit in rq[u % U] until they are stored to LDS during unit u - 1
                                                   // (static indices: the unit loop is unrolled U times)
 
@@ -246,8 +250,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino2hs_kernel(c
                 const __amdgpu_buffer_rsrc_t rs = unit_rsrc(cur, i + 1 < nch ? i + 1 : nch - 1);
 #pragma unroll
                 for (int k = 0; k < ITER_R; ++k) rq[(i + 1) % U][k] = stage_fetch(rs, roff[k]);
+                if (i < UW - 1 || (UW == 1 && i == 0)) {
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) aq[i][pp] = load_a(wb0 + (unsigned)(i < nch ? i : nch - 1) * w_unit, pp);
+                    for (int pp = 0; pp < 4; ++pp) aq[i % UW][pp] = load_a(wb0 + (unsigned)(i < nch ? i : nch - 1) * w_unit, pp);
+                }
             }
 #pragma unroll
             for (int k = 0; k < ITER_R; ++k) sR[r_slot[k]] = r0[k];
@@ -269,9 +275,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino2hs_kernel(c
                 for (int k = 0; k < ITER_R; ++k) sR[r_slot[k]] = rq[(K + 1) % U][k];
             }
             {   // requests for unit c + U - 1 (weights) / c + U (raw tile): clamped to the item's last unit (a harmless repeat)
-                const int cw = c + U - 1 < nch ? c + U - 1 : nch - 1;
+                if (!C::HALFROT) {
+                    const int cw = c + U - 1 < nch ? c + U - 1 : nch - 1;
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) aq[(K + U - 1) % U][pp] = load_a(wb0 + (unsigned)cw * w_unit, pp);
+                    for (int pp = 0; pp < 4; ++pp) aq[(K + U - 1) % UW][pp] = load_a(wb0 + (unsigned)cw * w_unit, pp);
+                }
                 const __amdgpu_buffer_rsrc_t rs = unit_rsrc(cur, c + U < nch ? c + U : nch - 1);
 #pragma unroll
                 for (int k = 0; k < ITER_R; ++k) rq[K][k] = stage_fetch(rs, roff[k]);      // (the slot of this unit's own raw tile: stored a unit ago)
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino2hs_kernel(c
 #define DCX_W2HS_MFMA_PAIR(P0)                                                                                              \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
                 _Pragma("unroll") for (int pp = (P0); pp < (P0) + 2; ++pp) {                                                \
-                    const float4 aa = aq[K][pp], bb = bq[pp];                                                               \
+                    const float4 aa = aq[K % UW][pp], bb = bq[pp];                                                               \
                     const float av = j == 0 ? aa.x : j == 1 ? aa.y : j == 2 ? aa.z : aa.w;                                  \
                     const float bv = j == 0 ? bb.x : j == 1 ? bb.y : j == 2 ? bb.z : bb.w;                                  \
                     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[pp]) : "v"(av), "v"(bv));               \
@@ -293,9 +301,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void dcx_conv_wino2hs_kernel(c
             }
             asm volatile("s_nop 1");
             DCX_W2HS_MFMA_PAIR(0)
+            const unsigned wb_n = wb0 + (unsigned)(has_next ? c + 1 : c) * w_unit;
+            if (C::HALFROT) { aq[0][0] = load_a(wb_n, 0); aq[0][1] = load_a(wb_n, 1); }
             __syncthreads();                         // raw tile of the next unit complete
             if (has_next) xform_read();
             DCX_W2HS_MFMA_PAIR(2)
+            if (C::HALFROT) { aq[0][2] = load_a(wb_n, 2); aq[0][3] = load_a(wb_n, 3); }
             if (has_next) xform_write(vnext);
         };
         for (int c0 = 0; c0 < nch; c0 += U) {

@@ -299,7 +299,7 @@ def test_kernel_family_depends_on_the_layer_only():
     from deepcharuco_amd import _lib
     L = _lib.lib()
     # (dcx_conv_wino2hs.h is the wino2h FAMILY -- the same summation orders -- in the shape for launches that cannot fill the chip)
-    fam = lambda nm: nm[nm.index("dcx_conv_") + 9:nm.index("_kernel")].replace("wino2hs", "wino2h")
+    fam = lambda nm: nm[nm.index("dcx_conv_") + 9:nm.index("_kernel")].replace("wino2hs", "wino2h").replace("wino2ps", "wino2p")
     det = [(64, 64, 1, 1), (64, 64, 2, 0), (64, 64, 2, 1), (64, 128, 4, 0), (128, 128, 4, 1), (128, 128, 8, 0), (128, 512, 8, 0)]
     ref = [(64, 64, 20, 0, 0, 0), (64, 128, 18, 0, 0, 0), (128, 128, 16, 1, 0, 0), (128, 128, 8, 0, 0, 0), (128, 128, 16, 0, 0, 1),
            (128, 128, 16, 0, 0, 0), (128, 64, 32, 0, 0, 1), (64, 64, 32, 0, 0, 0), (64, 64, 64, 0, 2, 1)]
