@@ -158,8 +158,11 @@ const CfgEntry* pick(int n, int cin, int ho, int wo, int cout_pad, int ks, int p
                                          // that still fits wins.  DCX_W2HS=<mask> restricts the choice (0: none; A/B runs)
                 static int w2hs = -1;     // bit mask of the cout-group counts in the choice (1 | 2 | 4)
                 if (w2hs < 0) { const char* e = getenv("DCX_W2HS"); w2hs = e ? atoi(e) : 7; }
-                if (!(w2hs & (c.cout_tile / 16)) || items > n_cu) continue;
+                static int w2hs_rounds = -1;      // DCX_W2HS_ROUNDS (experiments): launches of up to this many items per CU may use these kernels
+                if (w2hs_rounds < 0) { const char* e = getenv("DCX_W2HS_ROUNDS"); w2hs_rounds = e ? atoi(e) : 1; }
+                if (!(w2hs & (c.cout_tile / 16)) || items > (long)w2hs_rounds * n_cu) continue;
                 item_cost = (double)units * (8 * 64.0 * (c.cout_tile / 16) + 400.0) + 1200.0;
+                if (w2hs_rounds > 1 && items > n_cu) item_cost *= 0.8;      // (experiment: prefer them wherever they are allowed)
             }
             cost = (double)((items + n_cu - 1) / n_cu) * item_cost * (1.0 + 1e-6 * (double)items);   // ties: fewer work items
         } else if (c.fam == FAM_W2P) {   // 9 x 8 MFMAs of 32 cycles per unit; tiles are low-resolution, x4 phases

@@ -214,7 +214,7 @@ class GraphedPipeline:
                 graph.replay()
                 torch.cuda.current_stream().synchronize()
             res, counts = unpack_results(out_np, self.batch, self.pool, self.refinenet is not None)
-            need = int(counts.astype(np.int64).sum())
+            need = int(counts.sum(dtype=np.int64))
             if need > self.pool:                              # rare: more corners than the captured pool -> exact eager re-run
                 warnings.warn(f"the call produced {need} corners > the captured graph's pool={self.pool}; re-running eagerly with pool={need}")
                 res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need)

@@ -251,14 +251,14 @@ def unpack_results(packed: np.ndarray, batch: int, pool: int, refined: bool, con
     [p_loc, p_ids] in the same (id-sorted) order."""
     packed = np.asarray(packed, dtype=np.int32)
     counts = packed[:batch]
-    starts = packed[batch:2 * batch]
+    head = packed[:2 * batch].tolist()          # counts, starts as Python ints (the per-frame loop below is host-latency code: bs=1 calls)
     rows = packed[2 * batch:2 * batch + 4 * pool].reshape(pool, 4)
     xy = packed[2 * batch + 4 * pool:2 * batch + 6 * pool].view(np.float32).reshape(pool, 2)
     cf = packed[2 * batch + 6 * pool:2 * batch + 8 * pool].view(np.float32).reshape(pool, 2) if conf else None
     res: List[Optional[np.ndarray]] = []
     confs: List[Optional[np.ndarray]] = []
     for b in range(batch):
-        k, s0 = int(counts[b]), int(starts[b])
+        k, s0 = head[b], head[batch + b]
         if k == 0:
             res.append(np.array([]))
             confs.append(np.zeros((0, 2), np.float32))
@@ -267,15 +267,11 @@ def unpack_results(packed: np.ndarray, batch: int, pool: int, refined: bool, con
             res.append(None)
             confs.append(None)
             continue
-        ids = rows[s0:s0 + k, 2].astype(np.int64)
-        order = np.argsort(ids, kind="stable")
-        if refined:
-            a = np.empty((k, 3), np.float64)
-            a[:, 0:2] = xy[s0:s0 + k].astype(np.float64)
-        else:
-            a = np.empty((k, 3), np.int64)
-            a[:, 0:2] = rows[s0:s0 + k, 0:2]
-        a[:, 2] = ids
+        rb = rows[s0:s0 + k]
+        order = rb[:, 2].argsort(kind="stable")
+        a = np.empty((k, 3), np.float64 if refined else np.int64)
+        a[:, 0:2] = xy[s0:s0 + k] if refined else rb[:, 0:2]          # (the assignment widens: float32 -> float64 / int32 -> int64)
+        a[:, 2] = rb[:, 2]
         res.append(a[order])
         if conf:
             confs.append(cf[s0:s0 + k][order].copy())
