@@ -5,6 +5,8 @@
 //   * NCHW <-> C4 converters, stand-alone pre_image and argmax2d.
 #include "dcx_common.h"
 
+#include <stdlib.h>
+
 // pre_bgr_image /root/reference/src/models/model_utils.py:46-50: (float(g) - 128) / 255, IEEE division
 // (hipcc's default f32 division is correctly rounded; tests check all 256 inputs bit-for-bit).
 __device__ __forceinline__ float dcx_norm_u8(uint8_t g) { return ((float)g - 128.0f) / 255.0f; }
@@ -110,6 +112,75 @@ __global__ __launch_bounds__(256) void dcx_conv1_kernel(const uint8_t* __restric
     }
 }
 
+// conv1a for launches of one or two frames (the reference's bs=1 protocol): workgroup = a 16x16 tile of output pixels x 16 of the 64
+// channels (blockIdx.z).  The tile's 18x18 input pixels are decoded ONCE into LDS (BGR -> gray, normalise: three byte loads, an
+// integer dot product and an IEEE division per pixel) -- in dcx_conv1_kernel<PX, 4> every thread decodes its nine taps itself, 36
+// decodes per output pixel over the four channel quarters, which at bs=1 is half of the kernel's instructions (12.2 -> ~9 us for a
+// 320x240 BGR frame).  Same taps, same fmaf order, same bits.
+template <typename PX>
+__global__ __launch_bounds__(256) void dcx_conv1_tile_kernel(const uint8_t* __restrict__ in, long image_stride, int pitch,
+                                                               int h, int w, int pad,
+                                                               const float* __restrict__ w9x64,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ alpha,
+                                                               const float* __restrict__ beta,
+                                                               float* __restrict__ out, int ho, int wo, int tiles_y,
+                                                               int32_t* __restrict__ zero_words, int n_zero) {
+    __shared__ __attribute__((aligned(16))) float sw[9 * 64 + 3 * 64];
+    __shared__ float sp[18 * 18];
+    if (zero_words != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0;
+    const int tid = threadIdx.x;
+    const int n = (int)blockIdx.y / tiles_y, ty = (int)blockIdx.y - n * tiles_y, tx = (int)blockIdx.x;
+    for (int i = tid; i < 9 * 64; i += 256) sw[i] = w9x64[i];
+    if (tid < 64) {
+        sw[576 + tid] = bias[tid];
+        sw[640 + tid] = alpha[tid];
+        sw[704 + tid] = beta[tid];
+    }
+    const uint8_t* img = in + (size_t)n * image_stride;
+    for (int e = tid; e < 18 * 18; e += 256) {
+        const int i = e / 18, j = e - i * 18;
+        const int iy = ty * 16 - pad + i, ix = tx * 16 - pad + j;
+        const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+        const int cy = min(max(iy, 0), h - 1), cx = min(max(ix, 0), w - 1);
+        const float v = PX::load(img + (size_t)cy * pitch + (size_t)cx * PX::BPP);
+        sp[e] = inb ? v : 0.0f;       // zero padding of the NORMALISED image
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = tid & 15;
+    const int oy = ty * 16 + ly, ox = tx * 16 + lx;
+    if (oy >= ho || ox >= wo) return;
+    float x[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) x[dy * 3 + dx] = sp[(ly + dy) * 18 + lx + dx];
+    float4* out4 = reinterpret_cast<float4*>(out);
+    const float4* sw4 = reinterpret_cast<const float4*>(sw);
+    const int p = oy * wo + ox;
+    const int cq_lo = (int)blockIdx.z * 4;
+#pragma unroll
+    for (int cq = cq_lo; cq < cq_lo + 4; ++cq) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 wv = sw4[t * 16 + cq];
+            acc.x = fmaf(wv.x, x[t], acc.x);
+            acc.y = fmaf(wv.y, x[t], acc.y);
+            acc.z = fmaf(wv.z, x[t], acc.z);
+            acc.w = fmaf(wv.w, x[t], acc.w);
+        }
+        const float4 bi = sw4[144 + cq], al = sw4[160 + cq], be = sw4[176 + cq];
+        float4 y;
+        y.x = fmaxf(fmaf(acc.x + bi.x, al.x, be.x), 0.f);
+        y.y = fmaxf(fmaf(acc.y + bi.y, al.y, be.y), 0.f);
+        y.z = fmaxf(fmaf(acc.z + bi.z, al.z, be.z), 0.f);
+        y.w = fmaxf(fmaf(acc.w + bi.w, al.w, be.w), 0.f);
+        out4[((size_t)n * 16 + cq) * (size_t)(ho * wo) + p] = y;
+    }
+}
+
 // RefineNet conv1a for the pipeline: output pixel (oy, ox) of patch p reads patch pixels (oy + dy, ox + dx), i.e. image pixels
 // (y - 12 + oy + dy, x - 12 + ox + dx) of frame table[p].x around key-point (x, y) = table[p].(y, z), zero outside the image
 // (model_utils.py:19-36 pads the NORMALISED image with 0) -- the values dcx_gather_kernel would have written, the arithmetic of
@@ -212,7 +283,14 @@ static int launch_conv1(const uint8_t* in, long image_stride, int pitch, int n, 
     const unsigned gx = (unsigned)((ho * wo + 255) / 256), gy = (unsigned)(n < 65535 ? n : 65535);
     // few pixels in the launch (one or two 320x240 frames; n_limit launches are sized for their capacity and stay unsplit):
     // split the 64 channels over four workgroups so that the chip has enough waves in flight
-    if (n_limit == nullptr && (long)gx * gy < 1024)
+    // (DCX_CONV1_TILE=0: the round-5 form, every thread decoding its own nine taps -- A/B runs)
+    static int tile = -1;
+    if (tile < 0) { const char* e = getenv("DCX_CONV1_TILE"); tile = (e && !atoi(e)) ? 0 : 1; }
+    if (n_limit == nullptr && (long)gx * gy < 1024 && tile) {
+        const int tiles_x = (wo + 15) / 16, tiles_y = (ho + 15) / 16;
+        hipLaunchKernelGGL((dcx_conv1_tile_kernel<PX>), dim3((unsigned)tiles_x, (unsigned)(tiles_y * n), 4), dim3(256), 0, s, in, image_stride,
+                           pitch, h, w, pad, w9x64, bias, alpha, beta, out, ho, wo, tiles_y, zero_words, n_zero);
+    } else if (n_limit == nullptr && (long)gx * gy < 1024)
         hipLaunchKernelGGL((dcx_conv1_kernel<PX, 4>), dim3(gx, gy, 4), dim3(256), 0, s, in, image_stride, pitch, h, w, pad,
                            w9x64, bias, alpha, beta, out, ho, wo, n_limit, n, zero_words, n_zero);
     else
