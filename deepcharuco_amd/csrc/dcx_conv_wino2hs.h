@@ -19,10 +19,17 @@
 //   bits -- the matrix pipe would need every position in one wave's registers); with CG < 4 every workgroup of a tile repeats
 //   the tile's input transform (the CUs it runs on would otherwise idle).
 //
-// Per unit and thread: (CG = 4) at most one raw float4 of the next unit's 4 x 10 x 10 tile, ONE position of its transform
+// Per unit and thread (CG = 4): at most one raw float4 of a later unit's 4 x 10 x 10 tile, ONE position of the next unit's transform
 // (4 ds_read_b128, 6 v_pk ops, 1 ds_write_b128), 4 weight loads, 4 ds_read_b128 of transformed tiles, 16 MFMAs.  Two barriers per
-// unit as in dcx_conv_wino2h.h (raw tile complete / transformed tile complete); the next unit's raw tile and weights are requested
-// at the head of the unit.  Layouts, item walk and zero padding by buffer range are dcx_conv_wino2h.h's.
+// unit as in dcx_conv_wino2h.h (raw tile complete / transformed tile complete).  OPERANDS U - 1 UNITS AHEAD: a ring of U = 4 units
+// (static register indices, the unit loop is unrolled U times) holds the raw tiles of units c + 1 .. c + 3 and the weights of
+// c .. c + 2 -- at bs=1 nothing is warm (the input was written microseconds ago by other XCDs and comes back from the MALL, the
+// weights were last read a call ago: ~1 us either way), and with the one unit of lead of the bs=32 kernels every 512-cycle unit
+// waited for both (measured: bs=1 protocol 2,800 -> 2,855 calls/s with one unit of lead, -> 3,060 with three:
+// profiles/experiments/r06_bs1_split_positions.txt).  CG = 4 (128 registers per wave) keeps one weight set and refills a position
+// pair's registers as soon as its MFMAs are issued.  Work items are independent: prologue, nch units, epilogue, nothing carried
+// over (a cross-item pipeline was built and measured slower for these launches).  Layouts, item walk and zero padding by buffer
+// range are dcx_conv_wino2h.h's.
 #pragma once
 #include "dcx_conv_wino2h.h"
 

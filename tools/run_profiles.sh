@@ -32,6 +32,8 @@ if [ "$MODE" = collect ]; then
     timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}_cfg5" -o cfg5 -- $B --config cfg5 --steps 4 --warmup 2 --no-profile > "$OUT/rocprof_cfg5.log" 2>&1
     # bs=1 (the reference's own protocol): per-kernel times
     timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT/prof_r${R}_bs1" -o bs1 -- python $ROOT/tools/bs1_loop.py 60 1 > "$OUT/rocprof_bs1.log" 2>&1
+    timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE \
+        -d "$OUT/prof_r${R}_lds_bs1" -o lds -- python $ROOT/tools/bs1_loop.py 60 1 > "$OUT/rocprof_lds_bs1.log" 2>&1
     (cd "$ROOT" && timeout 200 python tools/stream_bench.py > "$OUT/stream_bench.log" 2>&1)
     (cd "$ROOT" && timeout 200 python tools/layer_table.py > "$OUT/layer_table.log" 2>&1)
     tail -1 "$OUT/bench.log"
@@ -49,6 +51,7 @@ else
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_write/write_results.db dcx_ > profiles/r${R}_pmc_write_size.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_sq/sq_results.db dcx_conv > profiles/r${R}_pmc_sq.txt
     python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_lds/lds_results.db dcx_conv > profiles/r${R}_pmc_lds_valu.txt
+    python tools/rocprof_pmc_summary.py gpurun_out/prof_r${R}_lds_bs1/lds_results.db dcx_conv > profiles/r${R}_pmc_lds_valu_bs1.txt
     grep '^{' gpurun_out/bench.log > profiles/r${R}_bench_n1.json
     grep -v "^\[\|Warning\|warn" gpurun_out/stream_bench.log > profiles/r${R}_stream_bench.txt
     cp gpurun_out/layer_table.log profiles/r${R}_layer_table.txt
