@@ -45,8 +45,12 @@ struct DcxWino2hsCfg {
     static constexpr int RAW = CQC * HH * RW;               // 400 float4 per unit
     static constexpr int ITER_R = (RAW + NTHREADS - 1) / NTHREADS;
     static constexpr int NUP = 4 / CG;                      // transform: positions (nu values) per thread
-    static constexpr int RP = RW + 2;                       // raw tile in LDS: dcx_conv_wino2h.h's 8x8 layout (conflict-free 16-lane groups)
-    __host__ __device__ static constexpr int raw_slot(int cq, int hy, int hx) { return (cq * HH + hy) * RP + hx + ((hy >> 2) & 1); }
+    // raw tile in LDS: row pitch 12, one slot of shift on every second row PAIR.  The transform reads float4 (row 2 ty + i, column
+    // 2 tx + j) with lane = (cq, tile): with the hardware's ds_read_b128 lane groups every group then covers 16 different 16-byte slots
+    // (tools/lds_sim.py; dcx_conv_wino2h.h's shift for the same tile -- (hy >> 2) & 1, built for its quarter-piece reads -- left a
+    // third of these reads two-way conflicted: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 18 % on the 16-cout variant)
+    static constexpr int RP = RW + 2;
+    __host__ __device__ static constexpr int raw_slot(int cq, int hy, int hx) { return (cq * HH + hy) * RP + hx + ((hy >> 1) & 1); }
     static constexpr int RAW_LDS = CQC * HH * RP;
     static constexpr int VPLANE = CQC * 16;                 // float4 per position: [cq][tile]
     static constexpr int LDS_V = 16 * VPLANE;               // one transformed buffer (16 KB)
