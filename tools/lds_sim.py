@@ -147,6 +147,47 @@ def wino2h(TH, TW, G=1, TB=2, dump="shared", RP=None, row_shift=None, col_of=Non
     return res
 
 
+def wino2hs(CG=4, shift=lambda hy: (hy >> 1) & 1, RP=12):
+    """dcx_conv_wino2hs.h (positions split over 4 CG waves): per unit -- the B operand reads of every wave, the raw-tile stores, the
+    one-position-per-thread (CG = 4) / two (CG = 2) / four (CG = 1) transform reads and writes; per ITEM -- the accumulator exchange."""
+    CQC, HH, RW = 4, 10, 10
+    VPLANE, LDSV = 64, 16 * 64
+    NW, NUP = 4 * CG, 4 // CG
+    slot = lambda cq, hy, hx: 2 * LDSV + (cq * HH + hy) * RP + hx + shift(hy)
+    res = {}
+
+    def add(name, kind, addrs):
+        t, e = cycles(kind, addrs)
+        r = res.setdefault(name, [0, 0]); r[0] += t; r[1] += e
+    RAW = CQC * HH * RW
+    for wv in range(NW):
+        pgp, cg = wv & 3, wv >> 2
+        for pp in range(4):
+            add("load_b", "read_b128", [16 * ((4 * pgp + pp) * VPLANE + l) for l in range(64)])
+        xi, ng = wv & 3, wv >> 2
+        ia, ib = (0, 1, 2, 1)[xi], (2, 2, 1, 3)[xi]
+        cols = list(range(4)) if NUP == 4 else [ng, ng + 1, ng + 2] if NUP == 2 else [(0, 1, 2, 1)[ng], (2, 2, 1, 3)[ng]]
+        for row in (ia, ib):
+            for c in cols:
+                add("xform_read", "read_b128", [16 * slot((l >> 4) & 3, 2 * ((l & 15) >> 2) + row, 2 * (l & 3) + c) for l in range(64)])
+        for nn in range(NUP):
+            add("xform_write", "write_b128", [16 * ((4 * xi + ng * NUP + nn) * VPLANE + ((l >> 4) & 3) * 16 + (l & 15)) for l in range(64)])
+        for pp in range(4):
+            add("exchange_write(item)", "write_b128", [16 * (((4 * pgp + pp) * (4 * CG) + cg * 4 + (l >> 4)) * 16 + (l & 15)) for l in range(64)])
+        for p in range(16):
+            add("exchange_read(item)", "read_b128", [16 * ((p * (4 * CG) + wv) * 16 + (l >> 2)) for l in range(64)])
+    for w0 in range(0, max(RAW, 64 * NW) if RAW > 64 * NW else RAW, 64):
+        ad = []
+        for l in range(64):
+            idx = w0 + l
+            if idx < RAW:
+                cq, hp = divmod(idx, HH * RW); hy, hx = divmod(hp, RW); ad.append(16 * slot(cq, hy, hx))
+            else:
+                ad.append(16 * (2 * LDSV + RP - 1))
+        add("raw_store", "write_b128", ad)
+    return res
+
+
 if __name__ == "__main__":
     contiguous = [list(range(i, i + 16)) for i in range(0, 64, 16)]
     for name, kw in (("guide groups", {}), ("contiguous 16-lane groups", dict(groups_b128=contiguous))):
@@ -157,4 +198,7 @@ if __name__ == "__main__":
         show("wino2h<8,8,TB1>", wino2h(8, 8, TB=1, **kw))
     GROUPS["read_b128"] = (G_B128R, 64, 16)
     # 6x20: even / odd column planes, plane row pitch 13, odd plane at +108, cq pitch 216
+    for cg in (4, 2, 1):
+        show(f"wino2hs<CG={cg}> row shift (hy >> 1) & 1", wino2hs(cg))
+        show(f"wino2hs<CG={cg}> with wino2h's shift (hy >> 2) & 1", wino2hs(cg, shift=lambda hy: (hy >> 2) & 1))
     show("wino2h<6,20> even/odd column planes", wino2h(6, 20, slot_of=lambda img, cq, hy, hx: cq * 216 + (hx & 1) * 108 + hy * 13 + (hx >> 1)))
