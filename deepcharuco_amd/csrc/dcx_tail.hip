@@ -28,6 +28,8 @@
 // logits while they are in the accumulators), delivered per corner -- the "confidences" model_utils.py:81-84 mentions.
 #include "dcx_common.h"
 
+int dcx_device_cu_count();   // dcx_conv_mfma.hip
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,6 +38,11 @@ typedef float dcx_t_f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int kTailPF = 2;   // prefetch distance in k-steps (measured at bs=32 with 32-cell items: 1 -> 30.8 us, 2 -> 29.4, 3 -> 30.7, 4 -> 31.9, 8 -> 37.1)
+#ifndef DCX_TAIL_PF_SMALL
+#define DCX_TAIL_PF_SMALL 8
+#endif
+constexpr int kTailPFSmall = DCX_TAIL_PF_SMALL;   // ... for launches of fewer work items than CUs (one frame): nothing else hides the latency of
+                                                  // operands that come from the MALL, and a k-step is 256 matrix cycles
 
 // Ordered compaction of ONE frame's packed codes into the batch's corner pool; all 256 threads of the workgroup call it.
 // Super-chunks of 2,048 cells: eight coalesced loads per thread in flight at once, wave ballots, per-(chunk, wave) counts through
@@ -120,7 +127,7 @@ __device__ __forceinline__ void dcx_tail_compact_frame(const int32_t* codes, int
     }
 }
 
-template <int NT, int IDS_TILES, bool CONF>
+template <int NT, int IDS_TILES, bool CONF, int PF = kTailPF>
 __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict__ act, int act_cq_total, int cells,
                                                         const float4* __restrict__ w_loc, const float* __restrict__ b_loc,
                                                         const float4* __restrict__ w_ids, const float* __restrict__ b_ids,
@@ -167,9 +174,9 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        float4 aq[32 + kTailPF], bq[32 + kTailPF][NT];
+        float4 aq[32 + PF], bq[32 + PF][NT];
 #pragma unroll
-        for (int st = 0; st < kTailPF; ++st) {
+        for (int st = 0; st < PF; ++st) {
             aq[st] = wq[w_lane + st * w_stride];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bq[st][nt] = act[a_off[nt] + st * k_stride];
@@ -177,10 +184,10 @@ __global__ __launch_bounds__(256) void dcx_tail_kernel(const float4* __restrict_
 #pragma unroll
         for (int st = 0; st < 32; ++st) {                    // st = 2 * chunk + s
             __builtin_amdgcn_sched_barrier(0);
-            if (st + kTailPF < 32) {
-                aq[st + kTailPF] = wq[w_lane + (st + kTailPF) * w_stride];
+            if (st + PF < 32) {
+                aq[st + PF] = wq[w_lane + (st + PF) * w_stride];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[st + kTailPF][nt] = act[a_off[nt] + (st + kTailPF) * k_stride];
+                for (int nt = 0; nt < NT; ++nt) bq[st + PF][nt] = act[a_off[nt] + (st + PF) * k_stride];
             }
             __builtin_amdgcn_sched_barrier(0);
             const float4 av = aq[st];
@@ -329,11 +336,14 @@ int dcx_launch_tail(const float* act, int batch, int cells, const float* w_loc, 
     const float4* a4 = reinterpret_cast<const float4*>(act);
     const float4* wl = reinterpret_cast<const float4*>(w_loc);
     const float4* wi = reinterpret_cast<const float4*>(w_ids);
-#define DCX_TAIL_LAUNCH(NT, IT, CF)                                                                                      \
-    hipLaunchKernelGGL((dcx_tail_kernel<NT, IT, CF>), dim3((unsigned)items), dim3(256), 0, s, a4, 128, cells, wl, b_loc, wi, b_ids, \
+#define DCX_TAIL_LAUNCH_PF(NT, IT, CF, PF)                                                                               \
+    hipLaunchKernelGGL((dcx_tail_kernel<NT, IT, CF, PF>), dim3((unsigned)items), dim3(256), 0, s, a4, 128, cells, wl, b_loc, wi, b_ids, \
                        ids_cout_pad, n_ids1, tiles, dust_bin, codes, loc_argmax, ids_argmax, po, dcx_tail_fence_mode())
+    const bool small = items < dcx_device_cu_count();       // one frame: 38 work items
+#define DCX_TAIL_LAUNCH(NT, IT, CF) do { if (small) DCX_TAIL_LAUNCH_PF(NT, IT, CF, kTailPFSmall); else DCX_TAIL_LAUNCH_PF(NT, IT, CF, kTailPF); } while (0)
     if (two) { if (conf) DCX_TAIL_LAUNCH(1, 2, true); else DCX_TAIL_LAUNCH(1, 2, false); }
     else     { if (conf) DCX_TAIL_LAUNCH(1, 1, true); else DCX_TAIL_LAUNCH(1, 1, false); }
 #undef DCX_TAIL_LAUNCH
+#undef DCX_TAIL_LAUNCH_PF
     return (int)hipGetLastError();
 }
