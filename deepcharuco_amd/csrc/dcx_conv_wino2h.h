@@ -50,11 +50,14 @@
 #ifndef DCX_W2H_DQB
 #define DCX_W2H_DQB 2
 #endif
+// (round 6: 9 / 14 -> 13 / 18.  The raw tile of the next unit is requested at event 0 and stored 128 matrix cycles per event later:
+//  at bs=1 -- three of a call's launches run this kernel at one workgroup per CU, operands from the MALL -- 1,150 cycles of lead left
+//  every unit waiting: bs=1 protocol +2 %; bs=32 unchanged, 10,265 vs 10,293 fps over three alternating rounds; 16 / 20 spills)
 #ifndef DCX_W2H_E_STORE
-#define DCX_W2H_E_STORE 9
+#define DCX_W2H_E_STORE 13
 #endif
 #ifndef DCX_W2H_E_XFORM
-#define DCX_W2H_E_XFORM 14
+#define DCX_W2H_E_XFORM 18
 #endif
 // the same for the TB = 1 kernels (16-tile items: launches that cannot fill the chip -- one workgroup per CU, nothing hides a
 // latency, and the operands come from the MALL / HBM rather than a warm L2): weights further ahead, the raw tile later.
