@@ -496,6 +496,21 @@ def test_stress_parity_slice(dev):
     assert hip["end_to_end"]["mismatched_frames"] <= o1["end_to_end"]["mismatched_frames"] + 2
 
 
+def test_one_frame_path_soak(dev):
+    """The one-frame path (round 6: the split-position kernel shapes of dcx_conv_wino2hs.h / dcx_conv_wino2ps.h under a hipGraph) in
+    the driver-run suite: 2 x 400 infer_image calls on the reference's photo, EVERY result compared with what the reference returned
+    (fixtures), and single frames of three sizes (incl. one that is not a multiple of 8) against the same frames inside a batch --
+    other kernel shapes of the same families, so the corner lists must be bit-identical (tools/bs1_soak.py; 2 x 20,000 calls and five
+    sizes on the builder's lease: profiles/experiments/r06_bs1_split_positions.txt 7.)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bs1_soak.py"), "400", "quick"], capture_output=True, text=True, timeout=600)
+    tail = "\n".join(r.stdout.strip().splitlines()[-8:])
+    assert r.returncode == 0 and "SOAK ok" in r.stdout, tail + r.stderr[-2000:]
+    assert r.stdout.count(" 0 results differ") == 2 and r.stdout.count(": 0 differ") == 3, tail
+    _report("one_frame_path_soak", {"calls_per_fixture": 400, "single_frame_sizes": 3, "differing": 0})
+
+
 @pytest.mark.parametrize("name", ["img7412_240x320", "img7412_diverse_240x320"])
 def test_real_photo_img7412_colour_paths(dev, name):
     """The reference's only real input -- the 320x240 colour photo its benchmark times (src/benchmark.py:34-35) -- against what the

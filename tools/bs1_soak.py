@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the one-frame path (the split-position kernels, hipGraph replay): every result of N infer_image calls on the reference's
 photo is compared with the reference's own answer (fixture), and single frames of other sizes / contents with the batched path
-(other kernels of the same families: must be bit-identical).   usage: python tools/bs1_soak.py [calls]"""
+(other kernels of the same families: must be bit-identical).   usage: python tools/bs1_soak.py [calls] [quick]"""
 import json
 import os
 import sys
@@ -18,6 +18,7 @@ from deepcharuco_amd.models.net import dcModel, lModel  # noqa: E402
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet  # noqa: E402
 
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+quick = len(sys.argv) > 2 and sys.argv[2] == "quick"
 dev = torch.device("cuda", 0)
 bad = 0
 for fxn in ("img7412_240x320.npz", "img7412_diverse_240x320.npz"):
@@ -47,7 +48,7 @@ for fxn in ("img7412_240x320.npz", "img7412_diverse_240x320.npz"):
     bad += nb
 # other single frames: infer_image (small-launch kernels, graph) vs the same frame inside a batch of 8 (bs=32-style kernels)
 rn = lRefineNet(RefineNet(W.synthetic_state_dict("refinenet", 1235), dev))
-for (h, w) in ((240, 320), (480, 640), (120, 160), (250, 330), (960, 1280)):
+for (h, w) in (((240, 320), (120, 160), (250, 330)) if quick else ((240, 320), (480, 640), (120, 160), (250, 330), (960, 1280))):
     frames = W.synthetic_frames("board", 77, 8, h, w)
     # dust-bin bias calibrated to ~16 firing cells per frame at this size (so that RefineNet, too, runs its one-frame launches)
     sd = WL.calibrate_dustbin(W.synthetic_state_dict("detector", 1234), torch.from_numpy(frames).to(dev), dev, diverse_ids=True)
