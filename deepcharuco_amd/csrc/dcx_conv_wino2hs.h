@@ -21,12 +21,12 @@
 //
 // Per unit and thread (CG = 4): at most one raw float4 of a later unit's 4 x 10 x 10 tile, ONE position of the next unit's transform
 // (4 ds_read_b128, 6 v_pk ops, 1 ds_write_b128), 4 weight loads, 4 ds_read_b128 of transformed tiles, 16 MFMAs.  Two barriers per
-// unit as in dcx_conv_wino2h.h (raw tile complete / transformed tile complete).  OPERANDS U - 1 UNITS AHEAD: a ring of U = 4 units
-// (static register indices, the unit loop is unrolled U times) holds the raw tiles of units c + 1 .. c + 3 and the weights of
-// c .. c + 2 -- at bs=1 nothing is warm (the input was written microseconds ago by other XCDs and comes back from the MALL, the
-// weights were last read a call ago: ~1 us either way), and with the one unit of lead of the bs=32 kernels every 512-cycle unit
-// waited for both (measured: bs=1 protocol 2,800 -> 2,855 calls/s with one unit of lead, -> 3,060 with three:
-// profiles/experiments/r06_bs1_split_positions.txt).  CG = 4 (128 registers per wave) keeps one weight set and refills a position
+// unit as in dcx_conv_wino2h.h (raw tile complete / transformed tile complete).  OPERANDS AT LEAST ONE FULL UNIT AHEAD: a ring of U
+// units (static register indices, the unit loop is unrolled U times) holds the raw tiles of units c + 1 .. c + U - 1 and the weights
+// of c .. c + U - 2 -- at bs=1 nothing is warm (the input was written microseconds ago by other XCDs and comes back from the MALL,
+// the weights were last read a call ago: ~1 us either way).  The first version requested a raw tile half a unit and the weights no
+// unit ahead of their use and every 512-cycle unit waited for both (bs=1 protocol 2,800 -> 2,855 calls/s; with the ring -> 3,060;
+// U = 2, 3, 4 measure the same: profiles/experiments/r06_bs1_split_positions.txt).  CG = 4 (128 registers per wave) keeps one weight set and refills a position
 // pair's registers as soon as its MFMAs are issued.  Work items are independent: prologue, nch units, epilogue, nothing carried
 // over (a cross-item pipeline was built and measured slower for these launches).  Layouts, item walk and zero padding by buffer
 // range are dcx_conv_wino2h.h's.
@@ -61,8 +61,8 @@ struct DcxWino2hsCfg {
 #define DCX_W2HS_U (CG == 4 ? 2 : 4)
 #endif
     static constexpr int U = DCX_W2HS_U;                    // units in flight (1..4): raw tiles / weights requested U - 1 units ahead.  At bs=1 the
-                                                            // operands come from the MALL (~1 us), not from a warm L2, and a unit of a 16-cout
-                                                            // workgroup is 512 matrix cycles: one unit of lead covered a third of the latency
+                                                            // operands come from the MALL (~1 us), not from a warm L2; what counts is a FULL
+                                                            // unit of lead (U = 2 .. 4 measure the same)
     static_assert(CG == 1 || CG == 2 || CG == 4, "1, 2 or 4 cout groups");
     static_assert(U >= 2 && U <= 4, "ring depth");
     // CG = 4 (1,024 threads: 128 registers per wave): ONE set of weight registers -- the next unit's weights of a position pair are
