@@ -153,6 +153,11 @@ class GraphedPipeline:
                 self._enqueue()
         self._in_np = self.pin_in.numpy()
         self._out_np = self.pin_out.numpy()
+        self._dev_index = self.dev.index
+        # views of the packed result for the one-frame unpack (inference.unpack_results' layout: counts, starts, rows, xy)
+        o, b, pool = self._out_np, batch, self.pool
+        self._rows_np = o[2 * b:2 * b + 4 * pool].reshape(pool, 4)
+        self._xy_np = o[2 * b + 4 * pool:2 * b + 6 * pool].view(np.float32).reshape(pool, 2)
         with _cache_lock:
             _live.add(self)           # every pipeline that exists, cached or evicted-but-still-held (drop_graphs_of_* close them all)
 
@@ -210,11 +215,30 @@ class GraphedPipeline:
             if frames.shape != in_np.shape or frames.dtype != np.uint8:
                 raise ValueError(f"expected uint8 frames of shape {in_np.shape}, got {frames.dtype} {frames.shape}")
             np.copyto(in_np, frames)
-            with torch.cuda.device(self.dev):
+            if _current_device() == self._dev_index:          # (the context manager costs 2 us of a 300 us call)
                 graph.replay()
-                torch.cuda.current_stream().synchronize()
-            res, counts = unpack_results(out_np, self.batch, self.pool, self.refinenet is not None)
-            need = int(counts.sum(dtype=np.int64))
+                _sync_current_stream(self._dev_index)
+            else:
+                with torch.cuda.device(self.dev):
+                    graph.replay()
+                    _sync_current_stream(self._dev_index)
+            if self.batch == 1:
+                # unpack_results for ONE frame on pre-built views (same values, same dtypes, same stable sort by id: inference.py:68-69)
+                need, s0 = out_np[:2].tolist()
+                if need == 0:
+                    res = [np.array([])]
+                elif s0 + need <= self.pool:
+                    rb = self._rows_np[s0:s0 + need]
+                    refined = self._ref is not None
+                    a = np.empty((need, 3), np.float64 if refined else np.int64)
+                    a[:, 0:2] = self._xy_np[s0:s0 + need] if refined else rb[:, 0:2]
+                    a[:, 2] = rb[:, 2]
+                    res = [a[rb[:, 2].argsort(kind="stable")]]
+                else:
+                    res = [None]
+            else:
+                res, counts = unpack_results(out_np, self.batch, self.pool, self.refinenet is not None)
+                need = int(counts.sum(dtype=np.int64))
             if need > self.pool:                              # rare: more corners than the captured pool -> exact eager re-run
                 warnings.warn(f"the call produced {need} corners > the captured graph's pool={self.pool}; re-running eagerly with pool={need}")
                 res = infer_batch(frames, self.dust_bin_ids, self.deepc, self.refinenet, pool=need)
@@ -237,6 +261,41 @@ class GraphedPipeline:
             self.close()
         except Exception:
             pass
+
+
+# ---- host-latency helpers of the one-frame path (a call is ~0.3 ms: every microsecond of interpreter work is 0.3 % of it) ----------
+_hip = None
+
+
+def _sync_current_stream(dev_index: int) -> None:
+    """hipStreamSynchronize on torch's CURRENT stream of the device (what ``torch.cuda.current_stream().synchronize()`` does, without
+    building a Stream object: 3.7 -> ~1 us per call, tools/bs1_host_probe2.py).  Falls back to the public API if torch's raw-stream
+    accessor or the HIP runtime's symbol is not where this build of torch has them."""
+    global _hip
+    if _hip is False:
+        torch.cuda.current_stream(dev_index).synchronize()
+        return
+    try:
+        raw = torch._C._cuda_getCurrentRawStream(dev_index)
+        if _hip is None:
+            import ctypes
+            lib = ctypes.CDLL("libamdhip64.so")            # the runtime torch has already loaded (same SONAME: same handle)
+            lib.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+            lib.hipStreamSynchronize.restype = ctypes.c_int
+            _hip = lib
+        rc = _hip.hipStreamSynchronize(raw)
+        if rc != 0:
+            raise RuntimeError(f"hipStreamSynchronize failed with hipError {rc}")
+    except (AttributeError, OSError):
+        _hip = False
+        torch.cuda.current_stream(dev_index).synchronize()
+
+
+def _current_device() -> int:
+    try:
+        return torch._C._cuda_getDevice()
+    except AttributeError:
+        return torch.cuda.current_device()
 
 
 _CACHE_MAX = 8        # per detector: graphs pin ~25 MB of workspace per 320x240 shape

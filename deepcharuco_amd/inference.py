@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .imgproc import bgr2gray
+from .imgproc import _opencv, bgr2gray
 from .models._handles import require_cuda
 from .models.model_utils import extract_patches, pre_bgr_image, pred_to_keypoints
 from .models.net import dcModel, lModel
@@ -319,6 +319,8 @@ def infer_batch(frames, dust_bin_ids: int, deepc, refinenet=None, kmax: int = DE
 
 
 _graph_state = {"enabled": None, "warned": False}
+_graph_mod = [None]          # deepcharuco_amd.graph, imported on first use
+_cuda_seen = [False]         # require_cuda("cuda") has passed once in this process
 
 
 def _graphs_enabled() -> bool:
@@ -341,18 +343,24 @@ def infer_image(img: np.ndarray, dust_bin_ids: int, deepc, refinenet=None, draw_
     staged path (``infer_image_staged``: host BGR->gray, no graph, the reference's three host syncs) has at hand; drawing needs
     OpenCV (ImportError without it, unless the frame has no detections: then the copy is returned undrawn, as the reference's
     helper would)."""
-    require_cuda(device)
-    from .imgproc import _opencv
+    if device != "cuda":           # ("cuda" = the current device; anything else is checked and resolved)
+        require_cuda(device)
+    elif not _cuda_seen[0]:
+        require_cuda(device)
+        _cuda_seen[0] = True
     if not isinstance(img, np.ndarray) or img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
         raise ValueError("expected a (H,W,3) uint8 BGR image")
     if draw_pred:      # debugging aid: the reference draws the UNREFINED detections too, which only the staged path has at hand
         return infer_image_staged(img, dust_bin_ids, deepc, refinenet, True, device)
     keypoints = None
     frame = bgr2gray(img)[None] if _opencv() else img[None]       # cv2 on the host (what the reference calls), else on the device
-    from .graph import graphs_usable
+    G = _graph_mod[0]
+    if G is None:
+        from . import graph as G       # (late: graph.py imports this module)
+        _graph_mod[0] = G
+    graphs_usable, cached_pipeline = G.graphs_usable, G.cached_pipeline
     if _graphs_enabled() and graphs_usable():
         try:
-            from .graph import cached_pipeline
             for attempt in (0, 1):
                 pipe = cached_pipeline(dust_bin_ids, deepc, refinenet, img.shape[0], img.shape[1], bgr=frame.ndim == 4)
                 try:

@@ -11,7 +11,16 @@ from .. import _lib
 from ..weights import StateDict, state_dict_keys, validate_state_dict
 
 
+_cuda_checked: dict = {}       # device argument -> resolved device, for arguments that name an index (a per-call cost on the one-frame path)
+
+
 def require_cuda(device) -> torch.device:
+    try:
+        hit = _cuda_checked.get(device)
+    except TypeError:           # unhashable argument: the slow path decides
+        hit = None
+    if hit is not None:
+        return hit
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError(
@@ -20,7 +29,11 @@ def require_cuda(device) -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError("deepcharuco_amd needs a visible ROCm GPU (torch.cuda.is_available() is False)")
     if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cuda", torch.cuda.current_device())      # follows the current device: not memoised
+    try:
+        _cuda_checked[device] = dev
+    except TypeError:
+        pass
     return dev
 
 
