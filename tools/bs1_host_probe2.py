@@ -1,10 +1,13 @@
+#!/usr/bin/env python3
+"""Where the host time of one GraphedPipeline.run goes: the body of the ROUND-5 form of run() (device context manager,
+torch.cuda.current_stream().synchronize(), generic unpack) with a timer after every statement, beside the product's run() and
+infer_image on the same pipeline (profiles/experiments/r06_bs1_split_positions.txt 5.).   usage: python tools/bs1_host_probe2.py"""
 import json, os, sys, time
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 from deepcharuco_amd import weights as W
-from deepcharuco_amd.graph import cached_pipeline, graphs_usable
-from deepcharuco_amd import inference as I
+from deepcharuco_amd.graph import cached_pipeline
 from deepcharuco_amd.inference import infer_image, unpack_results
 from deepcharuco_amd.models.net import dcModel, lModel
 from deepcharuco_amd.models.refinenet import RefineNet, lRefineNet
