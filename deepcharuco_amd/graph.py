@@ -283,12 +283,14 @@ def _sync_current_stream(dev_index: int) -> None:
             lib.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
             lib.hipStreamSynchronize.restype = ctypes.c_int
             _hip = lib
-        rc = _hip.hipStreamSynchronize(raw)
-        if rc != 0:
-            raise RuntimeError(f"hipStreamSynchronize failed with hipError {rc}")
+        if _hip.hipStreamSynchronize(raw) == 0:
+            return
     except (AttributeError, OSError):
-        _hip = False
-        torch.cuda.current_stream(dev_index).synchronize()
+        pass
+    # the shortcut is not usable in this process (no raw-stream accessor, no symbol, or a runtime that does not know torch's stream
+    # handle): the public API from here on -- it also raises a proper error if the stream itself is in trouble
+    _hip = False
+    torch.cuda.current_stream(dev_index).synchronize()
 
 
 def _current_device() -> int:
